@@ -1,0 +1,204 @@
+/*
+ * rtx.h -- C ABI of the MI355X renderer for the per-pixel trace loop.
+ *
+ * The reference renderer has no FFI or plug-in seam: its hot path is the OpenMP pixel loop of
+ * raytrace() (src/main.cpp:126-133 in the reference tree), which reads everything a SceneReader
+ * holds after readScene() + Camera::updateAxes() (src/main.cpp:110-112) and fills an Image3f
+ * (src/main.cpp:119,131).  This header cuts the boundary around that whole loop: plain pointers
+ * and sizes in, a float RGB framebuffer (and optionally the primary-hit primitive index map) out.
+ * No C++ or torch types cross it; every entry point returns 0 on success or a negative RTX_E_* code,
+ * and no exception ever leaves the library.
+ *
+ * Two layers:
+ *   rtx_scene_*  host-side scene layer (the reference's SceneReader: .test parser, transform stack,
+ *                materials, lights, camera) producing flat arrays;
+ *   rtx_*        the device layer: upload, regular-grid build on the GPU, render.
+ * A context is bound to one GPU and is not thread-safe; use one context per GPU (one process per
+ * GPU in the multi-GPU launch, each rendering its interleaved row tiles).
+ */
+#ifndef RTX_H_
+#define RTX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_OK            0
+#define RTX_E_INVALID    -1   /* bad argument (null pointer, out-of-range index or size)        */
+#define RTX_E_IO         -2   /* scene file could not be opened / image could not be written    */
+#define RTX_E_DEVICE     -3   /* a HIP runtime call failed (rtx_last_error() has the detail)    */
+#define RTX_E_STATE      -4   /* call order violated (e.g. render before scene/grid are set)    */
+#define RTX_E_NOMEM      -5   /* host or device allocation failed                               */
+#define RTX_E_LIMIT      -6   /* size beyond a documented maximum                               */
+
+const char* rtx_strerror(int code);
+/* Detail text of the most recent failing call on this thread ("" if none). */
+const char* rtx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat scene description (borrowed host pointers; every rtx_* call that takes a view copies what it
+ * needs before returning).  Replaces the object graph SceneReader owns: `geometries` (heap Triangle /
+ * Sphere objects, each carrying its own Material and mat4, src/readScene.h:104-123), `lights`
+ * (src/readScene.h:79-96).  Primitive order is file order; a primitive's index is its identity
+ * (the reference's only identity is the Material* inside each primitive, src/geometries.h:234,308).
+ * ---------------------------------------------------------------------------------------------- */
+#define RTX_PRIM_TRIANGLE 0
+#define RTX_PRIM_SPHERE   1
+#define RTX_LIGHT_POINT        0   /* LightType::POINT        src/geometries.h:354-357 */
+#define RTX_LIGHT_DIRECTIONAL  1   /* LightType::DIRECTIONAL                           */
+
+typedef struct rtx_scene_view {
+    int32_t n_prims, n_xforms, n_materials, n_lights;
+    const int32_t* prim_kind;      /* [n_prims] RTX_PRIM_*                                               */
+    const float*   prim_geom;      /* [n_prims][9]  triangle: A,B,C (object space); sphere: centre, r, 0 */
+    const int32_t* prim_xform;     /* [n_prims] index into xforms                                        */
+    const int32_t* prim_material;  /* [n_prims] index into materials                                     */
+    const float*   xforms;         /* [n_xforms][16] object->world, column-major (glm::mat4 layout)      */
+    const float*   materials;      /* [n_materials][13] ambient, diffuse, specular, emission (rgb), shininess
+                                      (struct Material, src/geometries.h:38-56)                           */
+    const float*   lights;         /* [n_lights][10] kind, position-or-direction xyz, colour rgb, attenuation
+                                      c0 c1 c2 (struct Light, src/geometries.h:359-364)                   */
+} rtx_scene_view;
+
+/* struct Camera as parsed (src/geometries.h:321-330); the frame axes of Camera::updateAxes() (:332-337)
+ * are derived inside the library. */
+typedef struct rtx_camera {
+    float eye[3], center[3], up[3];
+    float fov_deg;
+} rtx_camera;
+
+/* ------------------------------------------------------------------------------------------------
+ * Host scene layer -- replaces SceneReader::readScene(filename, useGrid) (src/readScene.h:45-182).
+ * Same directives, same defaults (diffuse 1 1 1, others 0, attenuation 1 0 0, shininess 40,
+ * :46-51), same silent ignoring of unknown directives (`maxdepth`, `maxverts`, comments, :172-173).
+ * Differences: an unreadable file is an error (RTX_E_IO) instead of an empty scene (:57-59), and
+ * vertex indices are range-checked (RTX_E_INVALID) instead of read unchecked (:108).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rtx_scene rtx_scene;
+
+int  rtx_scene_load(rtx_scene** out, const char* path);
+/* Parses scene text held in memory (same grammar as a .test file). */
+int  rtx_scene_parse(rtx_scene** out, const char* text, int64_t n_bytes);
+void rtx_scene_free(rtx_scene* s);
+/* The arrays stay owned by the scene and valid until rtx_scene_free(). */
+int  rtx_scene_get_view(const rtx_scene* s, rtx_scene_view* out);
+int  rtx_scene_get_camera(const rtx_scene* s, rtx_camera* out);
+/* `size` directive (src/readScene.h:69-72); 0 x 0 if the file has none. */
+int  rtx_scene_get_size(const rtx_scene* s, int32_t* width, int32_t* height);
+/* `output` directive (:169-171); "" if absent.  Owned by the scene. */
+const char* rtx_scene_get_output(const rtx_scene* s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device layer
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rtx_ctx rtx_ctx;
+
+/* Binds a context to GPU `device_id`.  Fails with RTX_E_DEVICE when no HIP device is usable:
+ * there is no CPU fallback. */
+int  rtx_create(rtx_ctx** out, int device_id);
+void rtx_destroy(rtx_ctx* ctx);
+
+/* Uploads the scene (replaces the geometry/light state trace() reads through SceneReader&,
+ * src/main.cpp:47-107).  Derived per-primitive data (edge vectors, triangle normals, per-transform
+ * inverses, glm::inverse call sites src/geometries.h:28,179-180) is computed once here. */
+int  rtx_set_scene(rtx_ctx* ctx, const rtx_scene_view* view);
+
+/* Grid::Grid (src/grid.h:36-49) on the GPU: per-primitive world boxes, scene bounds, then count /
+ * prefix-scan / scatter of primitive references into rx*ry*rz cells.
+ *   RTX_GRID_REFERENCE  cell lists exactly as the reference bins them (boxes whose maximum is seeded with
+ *                       FLT_MIN, src/geometries.h:146-152; bounds padded by 0.001, src/grid.h:31);
+ *                       needed by RTX_SEARCH_REFERENCE_LISTS.
+ *   RTX_GRID_NESTED     additionally a fine grid of (rx*sub, ry*sub, rz*sub) cells nested in the coarse
+ *                       cells, binned by tight boxes; needed by RTX_SEARCH_NESTED.  sub in [1, 64];
+ *                       sub = 0 lets the library choose from the primitive count.
+ * The reference always uses rx = ry = rz = 15 (src/grid.h:37). */
+#define RTX_GRID_REFERENCE 1u
+#define RTX_GRID_NESTED    2u
+int  rtx_build_grid(rtx_ctx* ctx, int32_t rx, int32_t ry, int32_t rz, int32_t sub, uint32_t flags);
+
+typedef struct rtx_grid_info {
+    float   lo[3], hi[3];          /* Grid::start_pos / end_pos (src/grid.h:12-13)                 */
+    int32_t rx, ry, rz, sub;
+    int64_t n_cells, n_refs;       /* coarse cells, references in the reference lists (0 if not built) */
+    int64_t n_fine_cells, n_fine_refs;
+    float   build_ms;              /* GPU time of the last rtx_build_grid                           */
+} rtx_grid_info;
+int  rtx_get_grid_info(const rtx_ctx* ctx, rtx_grid_info* out);
+/* Copies a grid's CSR arrays to the host.  which = RTX_GRID_REFERENCE or RTX_GRID_NESTED.
+ * cell_start has n_cells+1 (n_fine_cells+1) entries, prim_ids n_refs (n_fine_refs).  Cell (x,y,z) is
+ * entry x + rx*y + rx*ry*z (Grid::getOffsetAtIndices, src/grid.h:61-63).  Within a cell the ids are
+ * ascending, i.e. in file order as in the reference (src/grid.h:46-48,65-68). */
+int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, int32_t* prim_ids);
+
+/* How the primitives of one coarse cell are searched (Container::intersect, src/geometries.h:173-204):
+ *   RTX_SEARCH_REFERENCE_LISTS  every primitive in the reference's cell list is tested (the reference's work);
+ *   RTX_SEARCH_NESTED           a 3D-DDA over the fine cells nested in the coarse cell visits only primitives
+ *                               near the ray; same per-primitive arithmetic and acceptance rule, so the same
+ *                               nearest hit.
+ * The coarse walk (Grid::traverseGrid, src/grid.h:149-257) is identical in both. */
+#define RTX_SEARCH_REFERENCE_LISTS 0
+#define RTX_SEARCH_NESTED          1
+
+#define RTX_RENDER_COUNT_WORK 1u   /* run the instrumented kernels and fill the work counters of rtx_stats */
+
+typedef struct rtx_render_params {
+    int32_t  width, height;        /* full image; y = 0 is the top row (src/main.cpp:127-131)           */
+    int32_t  max_depth;            /* recursion budget of trace(); the reference always passes 5 (:131)  */
+    float    eps_bias;             /* SceneReader::epsilonBias = 0.001f (src/readScene.h:37)            */
+    int32_t  search;               /* RTX_SEARCH_*                                                      */
+    int32_t  tile_rows;            /* rows per tile of the multi-GPU split; <= 0 means 8                */
+    int32_t  rank, world;          /* this context renders tiles t with t % world == rank; 0,1 = all    */
+    uint32_t flags;                /* RTX_RENDER_*                                                      */
+} rtx_render_params;
+
+typedef struct rtx_stats {
+    /* rays = calls the reference would make to scene_content->intersect (src/main.cpp:57,70,82) */
+    int64_t primary_rays, shadow_rays, reflection_rays;
+    int64_t hits_per_level[16];
+    /* filled only with RTX_RENDER_COUNT_WORK */
+    int64_t tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits;
+    float   frame_ms;              /* first kernel to framebuffer complete on the device (HIP events)     */
+    float   trace_ms, shade_ms, resolve_ms;   /* per kernel family, summed over levels                   */
+    int32_t trace_launches, shade_launches, resolve_launches;
+} rtx_stats;
+
+/* Number of image rows this rank renders, and their global row numbers (ascending). rows may be NULL. */
+int  rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows);
+
+/* The pixel loop (src/main.cpp:126-133) for this rank's rows, results copied to the host.
+ * rgb_out: width*height*3 floats, row-major, RGB, y = 0 top -- only this rank's rows are written.
+ * prim_id_out (nullable): width*height, primary-hit primitive index, -1 = miss. */
+int  rtx_render(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
+                float* rgb_out, int32_t* prim_id_out, rtx_stats* stats);
+
+/* Same, leaving the result on the device: d_rgb_local is n_local_rows*width*3 floats of DEVICE memory,
+ * d_prim_id_local (nullable) n_local_rows*width int32, rows in the order rtx_local_rows() reports.
+ * Work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT waited for, except that
+ * `stats` (nullable) forces a wait at the end of the call so the numbers are final. */
+int  rtx_render_device(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
+                       float* d_rgb_local, int32_t* d_prim_id_local, void* stream, rtx_stats* stats);
+
+/* Single-ray probes for tests: the device evaluates Grid::intersect (src/grid.h:259-261) for n rays.
+ * origins/dirs: [n][3] host floats (directions are used as given, not normalised); t_limit: [n] or NULL
+ * (= FLT_MAX).  out_t [n], out_prim [n] (-1 = miss), out_pos / out_normal [n][3] (nullable). */
+int  rtx_intersect(rtx_ctx* ctx, int32_t search, int32_t n, const float* origins, const float* dirs,
+                   const float* t_limit, float* out_t, int32_t* out_prim, float* out_pos, float* out_normal);
+
+/* Camera::getRayAt (src/geometries.h:339-351) for n pixels, evaluated on the device: xy [n][2] -> dirs [n][3]. */
+int  rtx_camera_rays(rtx_ctx* ctx, const rtx_camera* cam, int32_t width, int32_t height, int32_t n,
+                     const int32_t* xy, float* dirs);
+
+/* ------------------------------------------------------------------------------------------------
+ * Image output -- replaces Image3f::write3fPpm / save (src/Image3f.h:63-80,128-133,154-170) without OpenCV.
+ * Conversion to 8 bits truncates, (unsigned char)(clamp(c) * 255), as the reference does (:72-74,163-165).
+ * ---------------------------------------------------------------------------------------------- */
+int  rtx_quantize(const float* rgb, int64_t n_values, uint8_t* out);
+/* Format by extension: .png (8-bit RGB, zlib deflate) or .ppm (P6). */
+int  rtx_save_image(const char* path, const float* rgb, int32_t width, int32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H_ */

@@ -1,0 +1,1131 @@
+// Device layer of librtx: scene upload, regular-grid build on the GPU (count / prefix-scan / scatter),
+// and the per-pixel trace loop as wavefront ray queues for gfx950.
+//
+// Frame structure (replaces the recursive trace() of src/main.cpp:81-107 in the reference tree):
+//   level d = 0 .. max_depth
+//     trace kernel   rays of level d (camera rays for d = 0, mirror rays otherwise) -> nearest hit;
+//                    each hit appends a hit record and, while d < max_depth, its mirror ray for level d+1
+//     shade kernel   per hit record: one shadow ray per light, Blinn-Phong, L_d = (ambient + emission) + shadow
+//   resolve kernels  from the deepest level up: C_d = clampRGB(L_d + specular * C_{d+1}); level 0 writes the pixel
+// Every queue lives in device memory; counts stay on the device (kernels read them), so a frame needs no
+// host synchronisation until its end.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rtx.h"
+#include "rtx_internal.h"
+#include "rt_math.h"
+#include "rt_xform.h"
+#include "rtx_traverse.h"
+
+using namespace rt;
+
+#define RTX_MAX_LEVELS 16          // max_depth <= 15
+#define RTX_BLOCK 256
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            rtx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return RTX_E_DEVICE;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// device-side frame description
+// ---------------------------------------------------------------------------------------------------
+struct DevCamera {
+    f3 eye, u, v, w;               // Camera::updateAxes (src/geometries.h:332-337), computed on the host
+    float tanx, tany, halfW, halfH;
+};
+
+// counters[] layout (ints): [0,16) hits per level; [16,32) trace work cursor per level;
+// [32,48) shade work cursor per level; [48,64) resolve work cursor per level
+#define CNT_HITS 0
+#define CNT_TRACE_CUR 16
+#define CNT_SHADE_CUR 32
+#define CNT_RESOLVE_CUR 48
+#define CNT_TOTAL 64
+
+struct DevFrame {
+    int W, H;                      // full image
+    int n_local_rows;              // rows this rank renders
+    int tile_rows, rank, world;
+    int nbx;                       // 8-pixel column blocks per row
+    int n_items0;                  // level-0 work items (8x8 pixel blocks * 64)
+    int max_depth;
+    float bias;
+    DevCamera cam;
+    float* rgb;                    // [n_local_rows][W][3]
+    int* ids;                      // [n_local_rows][W] or null
+    int* counters;
+    unsigned long long* work;      // WorkCounters as 7 x u64 (instrumented kernels only)
+    // hit records of the level being processed (reused by every level)
+    float4* hP;                    // position xyz, material index bits
+    float4* hN;                    // normal xyz, primitive index bits
+    float4* hD;                    // incoming ray direction as passed to trace() (not normalised)
+    int* pix0;                     // level 0: local pixel index per hit record
+    // persistent per level; the host fills in the pointers of the level a launch works on
+    float4* hL;                    // this level: L_d xyz (later C_d), material index bits
+    float4* hL_next;               // level d+1 (resolve only)
+    int* hChild;                   // this level: hit record of the mirror ray in level d+1, -1 = none
+    int* hChild_prev;              // level d-1 (trace only)
+    // mirror rays, ping-pong by level parity
+    float4* rO_in;                 // rays of this level (written by level d-1)
+    float4* rD_in;
+    float4* rO_out;                // rays for level d+1
+    float4* rD_out;
+};
+
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
+
+// One 64-ray chunk per call, handed out through an atomic cursor so that waves that drew cheap rays
+// come back for more.  Every wave reaches base >= n eventually because the cursor only grows.
+__device__ __forceinline__ int next_chunk(int* cursor) {
+    int base = 0;
+    if (wave_lane() == 0) base = atomicAdd(cursor, 64);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// Slot allocation for the lanes with `take` set: one atomic per wave.
+__device__ __forceinline__ int wave_alloc(int* counter, bool take) {
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) return -1;
+    const int lane = wave_lane();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    return take ? base + rank : -1;
+}
+
+__device__ __forceinline__ void flush_work(const WorkCounters& wc, unsigned long long* out) {
+    const unsigned long long v[7] = {wc.tri_tests, wc.sphere_tests, wc.xform_evals, wc.cell_steps,
+                                     wc.fine_steps, wc.light_evals, wc.nearest_hits};
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (wave_lane() == 0 && x) atomicAdd(out + k, x);
+    }
+}
+
+// Camera::getRayAt (src/geometries.h:339-351); tanx, tany, halfW, halfH are per-frame constants
+__device__ __forceinline__ f3 camera_ray(const DevCamera& c, int x, int y) {
+    const float j = (float)x + 0.5f;   // exact in fp32 for any image width below 2^22, as the reference's double add is
+    const float i = (float)y + 0.5f;
+    const float a = c.tanx * ((j - c.halfW) / c.halfW);
+    const float b = c.tany * ((c.halfH - i) / c.halfH);
+    return normalize3(a * c.u + b * c.v - c.w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// trace kernel: nearest hit for every ray of one level
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, DevGrid g, DevFrame f, int level) {
+    WorkCounters wc = {};
+    const int lane = wave_lane();
+    const int n = (level == 0) ? f.n_items0 : f.counters[CNT_HITS + level - 1];
+    for (;;) {
+        const int base = next_chunk(f.counters + CNT_TRACE_CUR + level);
+        if (base >= n) break;
+        const int i = base + lane;
+        bool active = i < n;
+        f3 O = mk(0, 0, 0), D = mk(0, 0, 1);
+        int pix = -1;
+        if (level == 0) {
+            // 64 consecutive work items = one 8x8 pixel block, so a wave's rays stay spatially coherent
+            const int blk = i >> 6, in = i & 63;
+            const int lr = 8 * (blk / f.nbx) + (in >> 3);
+            const int x = 8 * (blk % f.nbx) + (in & 7);
+            active = active && lr < f.n_local_rows && x < f.W;
+            if (active) {
+                const int tile = lr / f.tile_rows;
+                const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+                pix = lr * f.W + x;
+                O = f.cam.eye;
+                D = camera_ray(f.cam, x, y);
+            }
+        } else if (active) {
+            const float4 o = f.rO_in[i], d = f.rD_in[i];
+            O = mk(o.x, o.y, o.z);
+            D = mk(d.x, d.y, d.z);
+        }
+        float t = 0;
+        int prim = -1;
+        bool hit = false;
+        if (active) hit = traverse<MODE, false, COUNT>(sc, g, O, normalize3(D), FLT_MAX, t, prim, wc);   // src/main.cpp:82
+        const int slot = wave_alloc(f.counters + CNT_HITS + level, hit);
+        if (hit) {
+            if (COUNT) wc.nearest_hits++;
+            const f3 Dn = normalize3(D);
+            f3 P, N;
+            int material;
+            finish_hit(sc, prim, O, Dn, t, P, N, material);
+            f.hP[slot] = make_float4(P.x, P.y, P.z, as_float(material));
+            f.hN[slot] = make_float4(N.x, N.y, N.z, as_float(prim));
+            f.hD[slot] = make_float4(D.x, D.y, D.z, 0.0f);
+            f.hChild[slot] = -1;
+            if (level == 0) {
+                f.pix0[slot] = pix;
+                if (f.ids) f.ids[pix] = prim;
+            } else {
+                f.hChild_prev[i] = slot;
+            }
+            if (level < f.max_depth) {   // src/main.cpp:85-94
+                const f3 V = normalize3(-D);
+                const f3 R = (2.0f * dot3(V, N) * N) - V;
+                const f3 Po = P + f.bias * R;
+                f.rO_out[slot] = make_float4(Po.x, Po.y, Po.z, 0.0f);
+                f.rD_out[slot] = make_float4(R.x, R.y, R.z, 0.0f);
+            }
+        } else if (level == 0 && active) {   // src/main.cpp:104-106
+            f.rgb[3 * pix] = 0.0f;
+            f.rgb[3 * pix + 1] = 0.0f;
+            f.rgb[3 * pix + 2] = 0.0f;
+            if (f.ids) f.ids[pix] = -1;
+        }
+    }
+    if (COUNT) flush_work(wc, f.work);
+}
+
+// pow(max(x, 0), shininess) as the reference's host libm evaluates it: computed in fp64 and rounded once,
+// which agrees with a correctly rounded fp32 powf except in vanishingly rare double-rounding cases.
+__device__ __forceinline__ float pow_shine(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// calc_lighting (src/main.cpp:30-45)
+__device__ __forceinline__ f3 light_term(f3 rayDir, f3 L, f3 N, f3 kd, f3 ks, float shininess, f3 lc) {
+    const float lambert = clamp01(dot3(normalize3(L), N));
+    const f3 diff = kd * lc * lambert;
+    const f3 half = normalize3(normalize3(L) + normalize3(-rayDir));
+    const float ph = clamp01(dot3(half, N));
+    const float shine = pow_shine(sel_max(ph, 0.0f), shininess);
+    const f3 spec = ks * lc * shine;
+    return diff + spec;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shade kernel: shadowRayTest (src/main.cpp:47-79) per hit record, L = (ambient + emission) + shadow
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevGrid g, DevFrame f, int level) {
+    WorkCounters wc = {};
+    const int lane = wave_lane();
+    const int n = f.counters[CNT_HITS + level];
+    for (;;) {
+        const int base = next_chunk(f.counters + CNT_SHADE_CUR + level);
+        if (base >= n) break;
+        const int i = base + lane;
+        if (i < n) {
+        const float4 p4 = f.hP[i], n4 = f.hN[i], d4 = f.hD[i];
+        const f3 P = mk(p4.x, p4.y, p4.z), N = mk(n4.x, n4.y, n4.z), rayDir = mk(d4.x, d4.y, d4.z);
+        const int material = as_int(p4.w);
+        const float* m = sc.mats + 16 * material;
+        const f3 ka = mk(m[0], m[1], m[2]), kd = mk(m[3], m[4], m[5]), ks = mk(m[6], m[7], m[8]), ke = mk(m[9], m[10], m[11]);
+        const float shininess = m[12];
+        f3 acc = mk(0, 0, 0);
+        for (int l = 0; l < sc.n_lights; l++) {
+            const float* lt = sc.lights + 12 * l;
+            const f3 lpos = mk(lt[1], lt[2], lt[3]), lcol = mk(lt[4], lt[5], lt[6]);
+            float t;
+            int prim;
+            if ((int)lt[0] == RTX_LIGHT_POINT) {
+                const f3 L = normalize3(lpos - P);
+                const f3 So = P + f.bias * L;
+                const float tL = dot3(lpos - P, L);
+                if (!traverse<MODE, true, COUNT>(sc, g, So, L, tL, t, prim, wc)) {
+                    const float att = lt[7] + lt[8] * tL + lt[9] * tL * tL;
+                    if (COUNT) wc.light_evals++;
+                    acc = acc + light_term(rayDir, L, N, kd, ks, shininess, lcol) / att;
+                }
+            } else {
+                const f3 L = normalize3(lpos);
+                const f3 So = P + f.bias * L;
+                if (!traverse<MODE, true, COUNT>(sc, g, So, L, FLT_MAX, t, prim, wc)) {
+                    if (COUNT) wc.light_evals++;
+                    acc = acc + light_term(rayDir, L, N, kd, ks, shininess, lcol);
+                }
+            }
+        }
+        const f3 sh = clamp_rgb(acc);
+        const f3 Lsum = ka + ke + sh;   // src/main.cpp:99-101, left to right
+        f.hL[i] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+        }
+    }
+    if (COUNT) flush_work(wc, f.work);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// resolve kernel: the return path of trace(), C = clampRGB(L + specular * C_child) (src/main.cpp:99-102)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevScene sc, DevFrame f, int level) {
+    const int n = f.counters[CNT_HITS + level];
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < n; i += stride) {
+        const float4 l4 = f.hL[i];
+        const int material = as_int(l4.w);
+        const float* m = sc.mats + 16 * material;
+        const f3 ks = mk(m[6], m[7], m[8]);
+        f3 refl = mk(0, 0, 0);
+        if (level < f.max_depth) {
+            const int c = f.hChild[i];
+            if (c >= 0) {
+                const float4 c4 = f.hL_next[c];
+                refl = mk(c4.x, c4.y, c4.z);
+            }
+        }
+        const f3 C = clamp_rgb(mk(l4.x, l4.y, l4.z) + ks * refl);
+        if (level == 0) {
+            const int pix = f.pix0[i];
+            f.rgb[3 * pix] = C.x;
+            f.rgb[3 * pix + 1] = C.y;
+            f.rgb[3 * pix + 2] = C.z;
+        } else {
+            f.hL[i] = make_float4(C.x, C.y, C.z, l4.w);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// probes (tests): single rays through the grid, camera rays
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void k_probe(DevScene sc, DevGrid g, int n, const float* O, const float* D, const float* tl, float* out_t,
+                        int* out_prim, float* out_pos, float* out_n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    WorkCounters wc = {};
+    const f3 o = mk(O[3 * i], O[3 * i + 1], O[3 * i + 2]), d = mk(D[3 * i], D[3 * i + 1], D[3 * i + 2]);
+    float t = FLT_MAX;
+    int prim = -1;
+    const bool hit = traverse<MODE, false, false>(sc, g, o, d, tl ? tl[i] : FLT_MAX, t, prim, wc);
+    f3 P = mk(0, 0, 0), N = mk(0, 0, 0);
+    int material = -1;
+    if (hit) finish_hit(sc, prim, o, d, t, P, N, material);
+    out_t[i] = hit ? t : FLT_MAX;
+    out_prim[i] = hit ? prim : -1;
+    if (out_pos) { out_pos[3 * i] = P.x; out_pos[3 * i + 1] = P.y; out_pos[3 * i + 2] = P.z; }
+    if (out_n) { out_n[3 * i] = N.x; out_n[3 * i + 1] = N.y; out_n[3 * i + 2] = N.z; }
+}
+
+__global__ void k_camera_rays(DevCamera c, int n, const int* xy, float* dirs) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const f3 d = camera_ray(c, xy[2 * i], xy[2 * i + 1]);
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// grid build kernels
+// ---------------------------------------------------------------------------------------------------
+// World boxes of every primitive: `ref` as the reference computes them (8 transformed corners, minimum
+// seeded with FLT_MAX and maximum with FLT_MIN -- the smallest positive float, so every maximum is >= ~0;
+// src/geometries.h:122-155,253-259,313-318), `tight` with a true maximum seed.
+__global__ void k_boxes(int n, const float* geom, const int* kind, const int* xform, const float* xfwd, float* ref_box,
+                        float* tight_box) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float* gp = geom + 9 * i;
+    f3 lo, hi;
+    if (kind[i] == RTX_PRIM_TRIANGLE) {
+        const f3 A = mk(gp[0], gp[1], gp[2]), B = mk(gp[3], gp[4], gp[5]), C = mk(gp[6], gp[7], gp[8]);
+        lo = sel_min(sel_min(A, B), C);
+        hi = sel_max(sel_max(A, B), C);
+    } else {
+        const f3 S = mk(gp[0], gp[1], gp[2]), d = mk(gp[3], gp[3], gp[3]);
+        lo = S - d;
+        hi = S + d;
+    }
+    const float* m = xfwd + 16 * xform[i];
+    f3 rmin = mk(FLT_MAX, FLT_MAX, FLT_MAX), rmax = mk(FLT_MIN, FLT_MIN, FLT_MIN);
+    f3 tmin = rmin, tmax = mk(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int c = 0; c < 8; c++) {
+        const f3 corner = mk((c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z);
+        const f3 p = mul_point(m, corner);
+        rmin = sel_min(rmin, p);
+        rmax = sel_max(rmax, p);
+        tmin = sel_min(tmin, p);
+        tmax = sel_max(tmax, p);
+    }
+    float* r = ref_box + 6 * i;
+    r[0] = rmin.x; r[1] = rmin.y; r[2] = rmin.z; r[3] = rmax.x; r[4] = rmax.y; r[5] = rmax.z;
+    float* t = tight_box + 6 * i;
+    t[0] = tmin.x; t[1] = tmin.y; t[2] = tmin.z; t[3] = tmax.x; t[4] = tmax.y; t[5] = tmax.z;
+}
+
+// Grid::getSceneBounds (src/grid.h:21-34): min over (start, end), max over (end, start), then -+ 0.001.
+// One workgroup; min/max are exact, so the reduction order does not change the result.
+__global__ __launch_bounds__(1024) void k_scene_bounds(int n, const float* ref_box, float* bounds) {
+    __shared__ float smin[3][1024];
+    __shared__ float smax[3][1024];
+    const int tid = (int)threadIdx.x;
+    f3 mn = mk(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk(FLT_MIN, FLT_MIN, FLT_MIN);
+    for (int i = tid; i < n; i += 1024) {
+        const float* b = ref_box + 6 * i;
+        const f3 s = mk(b[0], b[1], b[2]), e = mk(b[3], b[4], b[5]);
+        mn = sel_min(sel_min(mn, s), e);
+        mx = sel_max(sel_max(mx, e), s);
+    }
+    smin[0][tid] = mn.x; smin[1][tid] = mn.y; smin[2][tid] = mn.z;
+    smax[0][tid] = mx.x; smax[1][tid] = mx.y; smax[2][tid] = mx.z;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            for (int a = 0; a < 3; a++) {
+                smin[a][tid] = sel_min(smin[a][tid], smin[a][tid + w]);
+                smax[a][tid] = sel_max(smax[a][tid], smax[a][tid + w]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float eps = 0.001f;
+        for (int a = 0; a < 3; a++) {
+            bounds[a] = smin[a][0] - eps;
+            bounds[3 + a] = smax[a][0] + eps;
+        }
+    }
+}
+
+struct BinParams {
+    f3 lo, size, res;              // getCellIndicesAtPosition operands (src/grid.h:53-59)
+    int rx, ry, rz;
+    float pad;                     // box growth (0 for the reference lists)
+};
+
+// Inclusive cell range of one box: clamp(floor((p - lo) * res / size), 0, res - 1) per corner and axis
+__device__ __forceinline__ void cell_range(const BinParams& bp, const float* box, int* c0, int* c1) {
+    const float lo[3] = {bp.lo.x, bp.lo.y, bp.lo.z}, size[3] = {bp.size.x, bp.size.y, bp.size.z};
+    const float res[3] = {bp.res.x, bp.res.y, bp.res.z};
+    for (int a = 0; a < 3; a++) {
+        c0[a] = (int)clampf(floorf(((box[a] - bp.pad) - lo[a]) * res[a] / size[a]), 0.0f, res[a] - 1.0f);
+        c1[a] = (int)clampf(floorf(((box[3 + a] + bp.pad) - lo[a]) * res[a] / size[a]), 0.0f, res[a] - 1.0f);
+    }
+}
+
+// pass 1 (FILL = false): count references per cell; pass 2 (FILL = true): scatter primitive ids,
+// Grid::placeIntoGrid (src/grid.h:76-88) for every primitive at once
+template <bool FILL>
+__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    int c0[3], c1[3];
+    cell_range(bp, boxes + 6 * i, c0, c1);
+    for (int z = c0[2]; z <= c1[2]; z++)
+        for (int y = c0[1]; y <= c1[1]; y++)
+            for (int x = c0[0]; x <= c1[0]; x++) {
+                const int cell = x + bp.rx * (y + bp.ry * z);
+                const int k = atomicAdd(count_or_cursor + cell, 1);
+                if (FILL) ids[start[cell] + k] = i;
+            }
+}
+
+// Exclusive prefix sum over the cell counts, one workgroup walking the array in 1024-wide strips.
+// start has n + 1 entries; start[n] = total.
+__global__ __launch_bounds__(1024) void k_scan(int n, const int* count, int* start) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? count[i] : 0;
+        buf[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = tid >= off ? buf[tid - off] : 0;
+            __syncthreads();
+            buf[tid] += add;
+            __syncthreads();
+        }
+        if (i < n) start[i] = carry + buf[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (tid == 0) start[n] = carry;
+}
+
+// Put every cell's ids in ascending (= file) order.  Short lists: one lane per cell, insertion sort.
+__global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_len) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1];
+    if (e - b < 2 || e - b > max_len) return;
+    for (int i = b + 1; i < e; i++) {
+        const int v = ids[i];
+        int j = i - 1;
+        while (j >= b && ids[j] > v) { ids[j + 1] = ids[j]; j--; }
+        ids[j + 1] = v;
+    }
+}
+// Long lists: one workgroup per cell; ids within a cell are distinct, so an element's final position is
+// the number of smaller elements (rank sort through a scratch copy).
+__global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* start, int* ids, int* scratch, int min_len) {
+    const int c = (int)blockIdx.x;
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1], len = e - b;
+    if (len <= min_len) return;
+    for (int i = (int)threadIdx.x; i < len; i += 256) scratch[b + i] = ids[b + i];
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < len; i += 256) {
+        const int v = scratch[b + i];
+        int rank = 0;
+        for (int j = 0; j < len; j++) rank += scratch[b + j] < v ? 1 : 0;
+        ids[b + rank] = v;
+    }
+}
+
+// coarse-cell occupancy of the nested grid
+__global__ void k_occupancy(int rx, int ry, int rz, int sub, const int* fstart, unsigned char* occ) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= rx * ry * rz) return;
+    const int ix = c % rx, iy = (c / rx) % ry, iz = c / (rx * ry);
+    const int frx = rx * sub, fry = ry * sub;
+    int any = 0;
+    for (int z = 0; z < sub && !any; z++)
+        for (int y = 0; y < sub && !any; y++) {
+            const int row = (ix * sub) + frx * ((iy * sub + y) + fry * (iz * sub + z));
+            any = fstart[row + sub] > fstart[row];   // lists of one x-run are contiguous in the CSR
+        }
+    occ[c] = (unsigned char)any;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int reserve(size_t count) {
+        if (count <= n && p) return RTX_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            rtx_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return RTX_E_NOMEM;
+        }
+        n = count;
+        return RTX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct rtx_ctx {
+    int device = 0;
+    int n_cus = 256;
+    // scene
+    bool have_scene = false;
+    int n_prims = 0, n_xforms = 0, n_materials = 0, n_lights = 0;
+    DevBuf<float4> prims, tri_normal;
+    DevBuf<float> xinv, xfwd, mats, lights, geom;
+    DevBuf<int> kind, xform;
+    // grid
+    bool have_ref = false, have_nested = false;
+    rtx_grid_info ginfo{};
+    DevBuf<float> ref_box, tight_box, bounds;
+    DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp;
+    DevBuf<unsigned char> cocc;
+    DevGrid dgrid{};
+    // frame workspace
+    size_t ws_pixels = 0;
+    int ws_levels = 0;
+    DevBuf<int> counters;
+    DevBuf<unsigned long long> work;
+    DevBuf<float4> hP, hN, hD, rO[2], rD[2], hL[RTX_MAX_LEVELS];
+    DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
+    DevBuf<float> rgb_local;
+    DevBuf<int> ids_local;
+    hipEvent_t ev[4 + 3 * 2 * RTX_MAX_LEVELS];
+    bool have_events = false;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+DevScene dev_scene(const rtx_ctx* c) {
+    DevScene s;
+    s.prims = c->prims.p;
+    s.tri_normal = c->tri_normal.p;
+    s.xinv = c->xinv.p;
+    s.mats = c->mats.p;
+    s.lights = c->lights.p;
+    s.n_prims = c->n_prims;
+    s.n_lights = c->n_lights;
+    return s;
+}
+
+int check_params(const rtx_render_params* p, int* tile_rows, int* rank, int* world) {
+    if (!p || p->width <= 0 || p->height <= 0) { rtx_set_error("render params: width/height must be positive"); return RTX_E_INVALID; }
+    if ((int64_t)p->width * p->height > (int64_t)1 << 28) { rtx_set_error("render params: more than 2^28 pixels"); return RTX_E_LIMIT; }
+    if (p->max_depth < 0 || p->max_depth >= RTX_MAX_LEVELS) { rtx_set_error("render params: max_depth must be in [0, %d]", RTX_MAX_LEVELS - 1); return RTX_E_LIMIT; }
+    *tile_rows = p->tile_rows > 0 ? p->tile_rows : 8;
+    *world = p->world > 0 ? p->world : 1;
+    *rank = p->rank;
+    if (*rank < 0 || *rank >= *world) { rtx_set_error("render params: rank %d outside world %d", *rank, *world); return RTX_E_INVALID; }
+    if (p->search != RTX_SEARCH_REFERENCE_LISTS && p->search != RTX_SEARCH_NESTED) { rtx_set_error("render params: unknown search mode %d", p->search); return RTX_E_INVALID; }
+    return RTX_OK;
+}
+
+int count_local_rows(int H, int tile_rows, int rank, int world) {
+    const int n_tiles = (H + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = rank; t < n_tiles; t += world) rows += std::min(tile_rows, H - t * tile_rows);
+    return rows;
+}
+
+// Camera::updateAxes (src/geometries.h:332-337) and the per-frame constants of getRayAt (:342-346)
+DevCamera make_camera(const rtx_camera* cam, int W, int H) {
+    DevCamera c;
+    const f3 eye = mk(cam->eye[0], cam->eye[1], cam->eye[2]);
+    const f3 center = mk(cam->center[0], cam->center[1], cam->center[2]);
+    const f3 up = mk(cam->up[0], cam->up[1], cam->up[2]);
+    const f3 dir = center - eye;
+    c.eye = eye;
+    c.w = normalize3(-dir);
+    c.u = normalize3(cross3(up, c.w));
+    c.v = normalize3(cross3(c.w, c.u));
+    const float pi = 3.14159265358979323846264338327950288f;
+    const float aspect = (float)W / (float)H;
+    c.tany = std::tan(cam->fov_deg * pi / 360.f);
+    c.tanx = c.tany * aspect;
+    c.halfW = (float)W / 2.f;
+    c.halfH = (float)H / 2.f;
+    return c;
+}
+
+int ensure_workspace(rtx_ctx* c, size_t pixels, int levels) {
+    if (pixels <= c->ws_pixels && levels <= c->ws_levels) return RTX_OK;
+    pixels = std::max(pixels, c->ws_pixels);
+    levels = std::max(levels, c->ws_levels);
+    int rc;
+    if ((rc = c->counters.reserve(CNT_TOTAL))) return rc;
+    if ((rc = c->work.reserve(8))) return rc;
+    if ((rc = c->hP.reserve(pixels)) || (rc = c->hN.reserve(pixels)) || (rc = c->hD.reserve(pixels))) return rc;
+    if ((rc = c->pix0.reserve(pixels))) return rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = c->rO[k].reserve(pixels)) || (rc = c->rD[k].reserve(pixels))) return rc;
+    for (int l = 0; l < levels; l++)
+        if ((rc = c->hL[l].reserve(pixels)) || (rc = c->hChild[l].reserve(pixels))) return rc;
+    c->ws_pixels = pixels;
+    c->ws_levels = levels;
+    return RTX_OK;
+}
+
+template <int MODE, bool COUNT>
+void launch_level(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level, int blocks, hipStream_t st, bool timed,
+                  hipEvent_t* ev) {
+    if (timed) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL((k_trace<MODE, COUNT>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, f, level);
+    if (timed) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL((k_shade<MODE, COUNT>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, f, level);
+    if (timed) (void)hipEventRecord(ev[2], st);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rtx_create(rtx_ctx** out, int device_id) {
+    if (!out) { rtx_set_error("rtx_create: null out pointer"); return RTX_E_INVALID; }
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        rtx_set_error("no usable HIP device (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return RTX_E_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n_dev) { rtx_set_error("rtx_create: device %d out of range (%d devices)", device_id, n_dev); return RTX_E_INVALID; }
+    rtx_ctx* c = new (std::nothrow) rtx_ctx;
+    if (!c) return RTX_E_NOMEM;
+    c->device = device_id;
+    DeviceGuard guard(device_id);
+    if (!guard.ok) { delete c; rtx_set_error("hipSetDevice(%d) failed", device_id); return RTX_E_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    for (auto& ev : c->ev) {
+        if (hipEventCreate(&ev) != hipSuccess) { delete c; rtx_set_error("hipEventCreate failed"); return RTX_E_DEVICE; }
+    }
+    c->have_events = true;
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx* c) {
+    if (!c) return;
+    DeviceGuard guard(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->have_events)
+        for (auto& ev : c->ev) (void)hipEventDestroy(ev);
+    c->prims.release(); c->tri_normal.release(); c->xinv.release(); c->xfwd.release(); c->mats.release();
+    c->lights.release(); c->geom.release(); c->kind.release(); c->xform.release();
+    c->ref_box.release(); c->tight_box.release(); c->bounds.release();
+    c->cstart.release(); c->cids.release(); c->fstart.release(); c->fids.release(); c->scratch_ids.release();
+    c->cell_tmp.release(); c->cocc.release();
+    c->counters.release(); c->work.release(); c->hP.release(); c->hN.release(); c->hD.release(); c->pix0.release();
+    for (int k = 0; k < 2; k++) { c->rO[k].release(); c->rD[k].release(); }
+    for (int l = 0; l < RTX_MAX_LEVELS; l++) { c->hL[l].release(); c->hChild[l].release(); }
+    c->rgb_local.release(); c->ids_local.release();
+    delete c;
+}
+
+int rtx_set_scene(rtx_ctx* c, const rtx_scene_view* v) {
+    if (!c || !v) { rtx_set_error("rtx_set_scene: null argument"); return RTX_E_INVALID; }
+    if (v->n_prims < 0 || v->n_xforms < 0 || v->n_materials < 0 || v->n_lights < 0) { rtx_set_error("rtx_set_scene: negative count"); return RTX_E_INVALID; }
+    if (v->n_prims > 0 && (!v->prim_kind || !v->prim_geom || !v->prim_xform || !v->prim_material || !v->xforms || !v->materials)) {
+        rtx_set_error("rtx_set_scene: null array with n_prims > 0");
+        return RTX_E_INVALID;
+    }
+    if (v->n_lights > 0 && !v->lights) { rtx_set_error("rtx_set_scene: null lights"); return RTX_E_INVALID; }
+    const int n = v->n_prims;
+    for (int i = 0; i < n; i++) {
+        if (v->prim_kind[i] != RTX_PRIM_TRIANGLE && v->prim_kind[i] != RTX_PRIM_SPHERE) { rtx_set_error("primitive %d: unknown kind %d", i, v->prim_kind[i]); return RTX_E_INVALID; }
+        if (v->prim_xform[i] < 0 || v->prim_xform[i] >= v->n_xforms) { rtx_set_error("primitive %d: transform index %d out of range", i, v->prim_xform[i]); return RTX_E_INVALID; }
+        if (v->prim_material[i] < 0 || v->prim_material[i] >= v->n_materials) { rtx_set_error("primitive %d: material index %d out of range", i, v->prim_material[i]); return RTX_E_INVALID; }
+    }
+    for (int l = 0; l < v->n_lights; l++) {
+        const int k = (int)v->lights[10 * l];
+        if (k != RTX_LIGHT_POINT && k != RTX_LIGHT_DIRECTIONAL) { rtx_set_error("light %d: unknown kind %d", l, k); return RTX_E_INVALID; }
+    }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+
+    std::vector<float4> prims, tn;
+    std::vector<float> xinv, mats, lights;
+    try {
+        prims.resize(3 * (size_t)std::max(n, 1));
+        tn.resize((size_t)std::max(n, 1));
+        xinv.resize(16 * (size_t)std::max(v->n_xforms, 1));
+        mats.assign(16 * (size_t)std::max(v->n_materials, 1), 0.0f);
+        lights.assign(12 * (size_t)std::max(v->n_lights, 1), 0.0f);
+    } catch (const std::bad_alloc&) {
+        return RTX_E_NOMEM;
+    }
+    for (int i = 0; i < n; i++) {
+        const float* gp = v->prim_geom + 9 * (size_t)i;
+        const float xf = as_float(v->prim_xform[i]), mt = as_float(v->prim_material[i]), kd = as_float(v->prim_kind[i]);
+        if (v->prim_kind[i] == RTX_PRIM_TRIANGLE) {
+            const f3 A = mk(gp[0], gp[1], gp[2]), B = mk(gp[3], gp[4], gp[5]), C = mk(gp[6], gp[7], gp[8]);
+            const f3 e1 = A - B, e2 = A - C;                       // src/geometries.h:306
+            const f3 nn = normalize3(cross3(B - A, C - A));        // src/geometries.h:308
+            prims[3 * (size_t)i] = make_float4(A.x, A.y, A.z, e1.x);
+            prims[3 * (size_t)i + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+            prims[3 * (size_t)i + 2] = make_float4(e2.z, xf, mt, kd);
+            tn[i] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+        } else {
+            prims[3 * (size_t)i] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+            prims[3 * (size_t)i + 1] = make_float4(0, 0, 0, 0);
+            prims[3 * (size_t)i + 2] = make_float4(0, xf, mt, kd);
+            tn[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+    for (int x = 0; x < v->n_xforms; x++) {
+        Mat4 m;
+        memcpy(m.m, v->xforms + 16 * (size_t)x, sizeof m.m);
+        const Mat4 inv = mat_inverse(m);
+        memcpy(&xinv[16 * (size_t)x], inv.m, sizeof inv.m);
+    }
+    for (int m = 0; m < v->n_materials; m++) memcpy(&mats[16 * (size_t)m], v->materials + 13 * (size_t)m, 13 * sizeof(float));
+    for (int l = 0; l < v->n_lights; l++) memcpy(&lights[12 * (size_t)l], v->lights + 10 * (size_t)l, 10 * sizeof(float));
+
+    int rc;
+    if ((rc = c->prims.reserve(prims.size())) || (rc = c->tri_normal.reserve(tn.size())) || (rc = c->xinv.reserve(xinv.size())) ||
+        (rc = c->xfwd.reserve(16 * (size_t)std::max(v->n_xforms, 1))) || (rc = c->mats.reserve(mats.size())) ||
+        (rc = c->lights.reserve(lights.size())) || (rc = c->geom.reserve(9 * (size_t)std::max(n, 1))) ||
+        (rc = c->kind.reserve((size_t)std::max(n, 1))) || (rc = c->xform.reserve((size_t)std::max(n, 1))))
+        return rc;
+    HIP_TRY(hipMemcpy(c->prims.p, prims.data(), prims.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->tri_normal.p, tn.data(), tn.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->xinv.p, xinv.data(), xinv.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->mats.p, mats.data(), mats.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->lights.p, lights.data(), lights.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (n > 0) {
+        HIP_TRY(hipMemcpy(c->geom.p, v->prim_geom, 9 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->kind.p, v->prim_kind, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->xform.p, v->prim_xform, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (v->n_xforms > 0) HIP_TRY(hipMemcpy(c->xfwd.p, v->xforms, 16 * (size_t)v->n_xforms * sizeof(float), hipMemcpyHostToDevice));
+    c->n_prims = n;
+    c->n_xforms = v->n_xforms;
+    c->n_materials = v->n_materials;
+    c->n_lights = v->n_lights;
+    c->have_scene = true;
+    c->have_ref = c->have_nested = false;
+    return RTX_OK;
+}
+
+// count -> scan -> scatter -> order, for one set of boxes and one resolution
+static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevBuf<int>& start, DevBuf<int>& ids, int64_t* n_refs) {
+    const int n = c->n_prims;
+    const int64_t n_cells64 = (int64_t)bp.rx * bp.ry * bp.rz;
+    if (n_cells64 > ((int64_t)1 << 27)) { rtx_set_error("grid of %lld cells exceeds the 2^27 cell limit", (long long)n_cells64); return RTX_E_LIMIT; }
+    const int n_cells = (int)n_cells64;
+    int rc;
+    if ((rc = start.reserve((size_t)n_cells + 1)) || (rc = c->cell_tmp.reserve((size_t)n_cells + 1))) return rc;
+    HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_cells + 1) * sizeof(int), 0));
+    const int pb = (n + 255) / 256;
+    if (n > 0) hipLaunchKernelGGL((k_bin<false>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_cells, c->cell_tmp.p, start.p);
+    int total = 0;
+    HIP_TRY(hipMemcpy(&total, start.p + n_cells, sizeof(int), hipMemcpyDeviceToHost));
+    if (total < 0) { rtx_set_error("cell reference count overflowed 2^31"); return RTX_E_LIMIT; }
+    if ((rc = ids.reserve((size_t)std::max(total, 1))) || (rc = c->scratch_ids.reserve((size_t)std::max(total, 1)))) return rc;
+    HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_cells + 1) * sizeof(int), 0));
+    if (n > 0) hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p);
+    hipLaunchKernelGGL(k_sort_small, dim3((n_cells + 255) / 256), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
+    hipLaunchKernelGGL(k_sort_large, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, c->scratch_ids.p, 24);
+    HIP_TRY(hipGetLastError());
+    *n_refs = total;
+    return RTX_OK;
+}
+
+int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, uint32_t flags) {
+    if (!c) { rtx_set_error("rtx_build_grid: null context"); return RTX_E_INVALID; }
+    if (!c->have_scene) { rtx_set_error("rtx_build_grid: no scene set"); return RTX_E_STATE; }
+    if (rx < 1 || ry < 1 || rz < 1 || rx > 1024 || ry > 1024 || rz > 1024) { rtx_set_error("rtx_build_grid: resolution must be in [1, 1024] per axis"); return RTX_E_INVALID; }
+    if (sub < 0 || sub > 64) { rtx_set_error("rtx_build_grid: sub must be in [0, 64]"); return RTX_E_INVALID; }
+    if (!(flags & (RTX_GRID_REFERENCE | RTX_GRID_NESTED))) { rtx_set_error("rtx_build_grid: no grid kind requested"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    const int n = c->n_prims;
+    int rc;
+    if ((rc = c->ref_box.reserve(6 * (size_t)std::max(n, 1))) || (rc = c->tight_box.reserve(6 * (size_t)std::max(n, 1))) || (rc = c->bounds.reserve(6))) return rc;
+
+    HIP_TRY(hipEventRecord(c->ev[0], 0));
+    if (n > 0)
+        hipLaunchKernelGGL(k_boxes, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float*)c->geom.p, (const int*)c->kind.p,
+                           (const int*)c->xform.p, (const float*)c->xfwd.p, c->ref_box.p, c->tight_box.p);
+    hipLaunchKernelGGL(k_scene_bounds, dim3(1), dim3(1024), 0, 0, n, (const float*)c->ref_box.p, c->bounds.p);
+    float b[6];
+    HIP_TRY(hipMemcpy(b, c->bounds.p, sizeof b, hipMemcpyDeviceToHost));
+
+    rtx_grid_info& gi = c->ginfo;
+    memset(&gi, 0, sizeof gi);
+    for (int a = 0; a < 3; a++) { gi.lo[a] = b[a]; gi.hi[a] = b[3 + a]; }
+    gi.rx = rx; gi.ry = ry; gi.rz = rz;
+    gi.n_cells = (int64_t)rx * ry * rz;
+
+    DevGrid& g = c->dgrid;
+    memset(&g, 0, sizeof g);
+    g.lo = mk(b[0], b[1], b[2]);
+    g.hi = mk(b[3], b[4], b[5]);
+    g.size = g.hi - g.lo;                                           // src/grid.h:41
+    g.res = mk((float)rx, (float)ry, (float)rz);
+    g.rx = rx; g.ry = ry; g.rz = rz;
+
+    c->have_ref = c->have_nested = false;
+    if (flags & RTX_GRID_REFERENCE) {
+        BinParams bp;
+        bp.lo = g.lo; bp.size = g.size; bp.res = g.res;
+        bp.rx = rx; bp.ry = ry; bp.rz = rz;
+        bp.pad = 0.0f;
+        if ((rc = build_lists(c, bp, c->ref_box.p, c->cstart, c->cids, &gi.n_refs))) return rc;
+        g.cstart = c->cstart.p;
+        g.cids = c->cids.p;
+        c->have_ref = true;
+    }
+    if (flags & RTX_GRID_NESTED) {
+        if (sub == 0) {
+            // aim at a few primitives per occupied fine cell: total fine cells ~ 8 x primitive count
+            const double target = std::cbrt(8.0 * std::max(n, 1) / ((double)rx * ry * rz));
+            sub = (int)std::min(32.0, std::max(1.0, std::ceil(target)));
+        }
+        const int frx = rx * sub, fry = ry * sub, frz = rz * sub;
+        BinParams bp;
+        bp.lo = g.lo; bp.size = g.size; bp.res = mk((float)frx, (float)fry, (float)frz);
+        bp.rx = frx; bp.ry = fry; bp.rz = frz;
+        bp.pad = 2e-4f * std::max(g.size.x, std::max(g.size.y, g.size.z));
+        if ((rc = build_lists(c, bp, c->tight_box.p, c->fstart, c->fids, &gi.n_fine_refs))) return rc;
+        if ((rc = c->cocc.reserve((size_t)gi.n_cells))) return rc;
+        hipLaunchKernelGGL(k_occupancy, dim3(((int)gi.n_cells + 255) / 256), dim3(256), 0, 0, rx, ry, rz, sub, (const int*)c->fstart.p, c->cocc.p);
+        g.sub = sub;
+        g.frx = frx; g.fry = fry; g.frz = frz;
+        g.fcell = mk(g.size.x / (float)frx, g.size.y / (float)fry, g.size.z / (float)frz);
+        g.inv_fcell = mk((float)frx / g.size.x, (float)fry / g.size.y, (float)frz / g.size.z);
+        g.fstart = c->fstart.p;
+        g.fids = c->fids.p;
+        g.cocc = c->cocc.p;
+        gi.sub = sub;
+        gi.n_fine_cells = (int64_t)frx * fry * frz;
+        c->have_nested = true;
+    }
+    HIP_TRY(hipEventRecord(c->ev[1], 0));
+    HIP_TRY(hipEventSynchronize(c->ev[1]));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    gi.build_ms = ms;
+    return RTX_OK;
+}
+
+int rtx_get_grid_info(const rtx_ctx* c, rtx_grid_info* out) {
+    if (!c || !out) { rtx_set_error("rtx_get_grid_info: null argument"); return RTX_E_INVALID; }
+    if (!c->have_ref && !c->have_nested) { rtx_set_error("rtx_get_grid_info: no grid built"); return RTX_E_STATE; }
+    *out = c->ginfo;
+    return RTX_OK;
+}
+
+int rtx_download_grid(const rtx_ctx* c, uint32_t which, int32_t* cell_start, int32_t* prim_ids) {
+    if (!c || !cell_start) { rtx_set_error("rtx_download_grid: null argument"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (which == RTX_GRID_REFERENCE) {
+        if (!c->have_ref) { rtx_set_error("rtx_download_grid: reference lists not built"); return RTX_E_STATE; }
+        HIP_TRY(hipMemcpy(cell_start, c->cstart.p, ((size_t)c->ginfo.n_cells + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        if (prim_ids && c->ginfo.n_refs > 0) HIP_TRY(hipMemcpy(prim_ids, c->cids.p, (size_t)c->ginfo.n_refs * sizeof(int), hipMemcpyDeviceToHost));
+    } else if (which == RTX_GRID_NESTED) {
+        if (!c->have_nested) { rtx_set_error("rtx_download_grid: nested lists not built"); return RTX_E_STATE; }
+        HIP_TRY(hipMemcpy(cell_start, c->fstart.p, ((size_t)c->ginfo.n_fine_cells + 1) * sizeof(int), hipMemcpyDeviceToHost));
+        if (prim_ids && c->ginfo.n_fine_refs > 0) HIP_TRY(hipMemcpy(prim_ids, c->fids.p, (size_t)c->ginfo.n_fine_refs * sizeof(int), hipMemcpyDeviceToHost));
+    } else {
+        rtx_set_error("rtx_download_grid: unknown grid kind %u", which);
+        return RTX_E_INVALID;
+    }
+    return RTX_OK;
+}
+
+int rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows) {
+    int tile_rows, rank, world;
+    int rc = check_params(p, &tile_rows, &rank, &world);
+    if (rc) return rc;
+    if (!n_rows) { rtx_set_error("rtx_local_rows: null n_rows"); return RTX_E_INVALID; }
+    const int n_tiles = (p->height + tile_rows - 1) / tile_rows;
+    int k = 0;
+    for (int t = rank; t < n_tiles; t += world)
+        for (int r = 0; r < tile_rows && t * tile_rows + r < p->height; r++) {
+            if (rows) rows[k] = t * tile_rows + r;
+            k++;
+        }
+    *n_rows = k;
+    return RTX_OK;
+}
+
+int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* d_rgb, int32_t* d_ids,
+                      void* stream, rtx_stats* stats) {
+    if (!c || !cam || !d_rgb) { rtx_set_error("rtx_render_device: null argument"); return RTX_E_INVALID; }
+    int tile_rows, rank, world;
+    int rc = check_params(p, &tile_rows, &rank, &world);
+    if (rc) return rc;
+    if (!c->have_scene) { rtx_set_error("render: no scene set"); return RTX_E_STATE; }
+    if (p->search == RTX_SEARCH_REFERENCE_LISTS && !c->have_ref) { rtx_set_error("render: reference cell lists not built"); return RTX_E_STATE; }
+    if (p->search == RTX_SEARCH_NESTED && !c->have_nested) { rtx_set_error("render: nested grid not built"); return RTX_E_STATE; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    hipStream_t st = (hipStream_t)stream;
+
+    const int nl = count_local_rows(p->height, tile_rows, rank, world);
+    const int levels = p->max_depth + 1;
+    const size_t pixels = (size_t)nl * p->width;
+    if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (nl == 0) return RTX_OK;
+
+    DevFrame f;
+    memset(&f, 0, sizeof f);
+    f.W = p->width; f.H = p->height;
+    f.n_local_rows = nl;
+    f.tile_rows = tile_rows; f.rank = rank; f.world = world;
+    f.nbx = (p->width + 7) / 8;
+    f.n_items0 = f.nbx * ((nl + 7) / 8) * 64;
+    f.max_depth = p->max_depth;
+    f.bias = p->eps_bias;
+    f.cam = make_camera(cam, p->width, p->height);
+    f.rgb = d_rgb;
+    f.ids = d_ids;
+    f.counters = c->counters.p;
+    f.work = c->work.p;
+    f.hP = c->hP.p; f.hN = c->hN.p; f.hD = c->hD.p; f.pix0 = c->pix0.p;
+
+    const DevScene sc = dev_scene(c);
+    const bool count = (p->flags & RTX_RENDER_COUNT_WORK) != 0;
+    const bool timed = stats != nullptr;
+    const int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the chunk cursor balances the rest
+
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
+    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 8 * sizeof(unsigned long long), st));
+    hipEvent_t* ev = c->ev;
+    HIP_TRY(hipEventRecord(ev[0], st));
+    for (int l = 0; l < levels; l++) {
+        hipEvent_t* le = ev + 4 + 3 * l;
+        f.hL = c->hL[l].p;
+        f.hChild = c->hChild[l].p;
+        f.hChild_prev = l > 0 ? c->hChild[l - 1].p : nullptr;
+        f.rO_in = c->rO[(l + 1) & 1].p; f.rD_in = c->rD[(l + 1) & 1].p;
+        f.rO_out = c->rO[l & 1].p; f.rD_out = c->rD[l & 1].p;
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) {
+            if (count) launch_level<RT_SEARCH_REF, true>(c, sc, f, l, blocks, st, timed, le);
+            else launch_level<RT_SEARCH_REF, false>(c, sc, f, l, blocks, st, timed, le);
+        } else {
+            if (count) launch_level<RT_SEARCH_NESTED, true>(c, sc, f, l, blocks, st, timed, le);
+            else launch_level<RT_SEARCH_NESTED, false>(c, sc, f, l, blocks, st, timed, le);
+        }
+    }
+    HIP_TRY(hipEventRecord(ev[1], st));
+    for (int l = levels - 1; l >= 0; l--) {
+        f.hL = c->hL[l].p;
+        f.hL_next = l + 1 < levels ? c->hL[l + 1].p : nullptr;
+        f.hChild = c->hChild[l].p;
+        hipLaunchKernelGGL(k_resolve, dim3(c->n_cus * 4), dim3(RTX_BLOCK), 0, st, sc, f, l);
+    }
+    HIP_TRY(hipEventRecord(ev[2], st));
+    HIP_TRY(hipGetLastError());
+
+    if (stats) {
+        HIP_TRY(hipEventSynchronize(ev[2]));
+        int cnt[CNT_TOTAL];
+        HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        stats->primary_rays = (int64_t)pixels;
+        for (int l = 0; l < levels; l++) {
+            stats->hits_per_level[l] = cnt[CNT_HITS + l];
+            stats->shadow_rays += (int64_t)cnt[CNT_HITS + l] * c->n_lights;
+            if (l < p->max_depth) stats->reflection_rays += cnt[CNT_HITS + l];
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ev[4 + 3 * l], ev[4 + 3 * l + 1]);
+            (void)hipEventElapsedTime(&b, ev[4 + 3 * l + 1], ev[4 + 3 * l + 2]);
+            stats->trace_ms += a;
+            stats->shade_ms += b;
+        }
+        stats->trace_launches = stats->shade_launches = stats->resolve_launches = levels;
+        (void)hipEventElapsedTime(&stats->frame_ms, ev[0], ev[2]);
+        (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
+        if (count) {
+            unsigned long long w[8];
+            HIP_TRY(hipMemcpy(w, c->work.p, sizeof w, hipMemcpyDeviceToHost));
+            stats->tri_tests = (int64_t)w[0]; stats->sphere_tests = (int64_t)w[1]; stats->xform_evals = (int64_t)w[2];
+            stats->cell_steps = (int64_t)w[3]; stats->fine_steps = (int64_t)w[4]; stats->light_evals = (int64_t)w[5];
+            stats->nearest_hits = (int64_t)w[6];
+        }
+    }
+    return RTX_OK;
+}
+
+int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* rgb_out, int32_t* prim_id_out, rtx_stats* stats) {
+    if (!c || !cam || !rgb_out) { rtx_set_error("rtx_render: null argument"); return RTX_E_INVALID; }
+    int tile_rows, rank, world;
+    int rc = check_params(p, &tile_rows, &rank, &world);
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    const int nl = count_local_rows(p->height, tile_rows, rank, world);
+    const size_t pixels = (size_t)nl * p->width;
+    if ((rc = c->rgb_local.reserve(std::max(pixels, (size_t)1) * 3))) return rc;
+    if (prim_id_out && (rc = c->ids_local.reserve(std::max(pixels, (size_t)1)))) return rc;
+    rtx_stats local_stats;
+    rc = rtx_render_device(c, cam, p, c->rgb_local.p, prim_id_out ? c->ids_local.p : nullptr, nullptr, stats ? stats : &local_stats);
+    if (rc) return rc;
+    if (nl == 0) return RTX_OK;
+    std::vector<int32_t> rows;
+    std::vector<float> rgb;
+    std::vector<int32_t> ids;
+    try {
+        rows.resize(nl);
+        rgb.resize(pixels * 3);
+        if (prim_id_out) ids.resize(pixels);
+    } catch (const std::bad_alloc&) {
+        return RTX_E_NOMEM;
+    }
+    int n_rows = 0;
+    rtx_local_rows(p, &n_rows, rows.data());
+    HIP_TRY(hipMemcpy(rgb.data(), c->rgb_local.p, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (prim_id_out) HIP_TRY(hipMemcpy(ids.data(), c->ids_local.p, pixels * sizeof(int), hipMemcpyDeviceToHost));
+    const size_t W = (size_t)p->width;
+    for (int r = 0; r < nl; r++) {
+        memcpy(rgb_out + (size_t)rows[r] * W * 3, rgb.data() + (size_t)r * W * 3, W * 3 * sizeof(float));
+        if (prim_id_out) memcpy(prim_id_out + (size_t)rows[r] * W, ids.data() + (size_t)r * W, W * sizeof(int32_t));
+    }
+    return RTX_OK;
+}
+
+int rtx_intersect(rtx_ctx* c, int32_t search, int32_t n, const float* O, const float* D, const float* tl, float* out_t,
+                  int32_t* out_prim, float* out_pos, float* out_n) {
+    if (!c || n < 0 || (n > 0 && (!O || !D || !out_t || !out_prim))) { rtx_set_error("rtx_intersect: bad argument"); return RTX_E_INVALID; }
+    if (!c->have_scene) { rtx_set_error("rtx_intersect: no scene set"); return RTX_E_STATE; }
+    if (search == RTX_SEARCH_REFERENCE_LISTS && !c->have_ref) { rtx_set_error("rtx_intersect: reference cell lists not built"); return RTX_E_STATE; }
+    if (search == RTX_SEARCH_NESTED && !c->have_nested) { rtx_set_error("rtx_intersect: nested grid not built"); return RTX_E_STATE; }
+    if (search != RTX_SEARCH_REFERENCE_LISTS && search != RTX_SEARCH_NESTED) { rtx_set_error("rtx_intersect: unknown search mode"); return RTX_E_INVALID; }
+    if (n == 0) return RTX_OK;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    DevBuf<float> dO, dD, dT, dOutT, dPos, dN;
+    DevBuf<int> dPrim;
+    int rc;
+    if ((rc = dO.reserve(3 * (size_t)n)) || (rc = dD.reserve(3 * (size_t)n)) || (rc = dT.reserve((size_t)n)) || (rc = dOutT.reserve((size_t)n)) ||
+        (rc = dPos.reserve(3 * (size_t)n)) || (rc = dN.reserve(3 * (size_t)n)) || (rc = dPrim.reserve((size_t)n)))
+        goto done;
+    rc = RTX_E_DEVICE;
+    if (hipMemcpy(dO.p, O, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) goto done;
+    if (hipMemcpy(dD.p, D, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) goto done;
+    if (tl && hipMemcpy(dT.p, tl, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) goto done;
+    {
+        const DevScene sc = dev_scene(c);
+        const int blocks = (n + 63) / 64;
+        if (search == RTX_SEARCH_REFERENCE_LISTS)
+            hipLaunchKernelGGL((k_probe<RT_SEARCH_REF>), dim3(blocks), dim3(64), 0, 0, sc, c->dgrid, n, (const float*)dO.p, (const float*)dD.p,
+                               tl ? (const float*)dT.p : (const float*)nullptr, dOutT.p, dPrim.p, dPos.p, dN.p);
+        else
+            hipLaunchKernelGGL((k_probe<RT_SEARCH_NESTED>), dim3(blocks), dim3(64), 0, 0, sc, c->dgrid, n, (const float*)dO.p, (const float*)dD.p,
+                               tl ? (const float*)dT.p : (const float*)nullptr, dOutT.p, dPrim.p, dPos.p, dN.p);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) goto done;
+    if (hipMemcpy(out_t, dOutT.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    if (hipMemcpy(out_prim, dPrim.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    if (out_pos && hipMemcpy(out_pos, dPos.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    if (out_n && hipMemcpy(out_n, dN.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) goto done;
+    rc = RTX_OK;
+done:
+    if (rc == RTX_E_DEVICE) rtx_set_error("rtx_intersect: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    dO.release(); dD.release(); dT.release(); dOutT.release(); dPos.release(); dN.release(); dPrim.release();
+    return rc;
+}
+
+int rtx_camera_rays(rtx_ctx* c, const rtx_camera* cam, int32_t W, int32_t H, int32_t n, const int32_t* xy, float* dirs) {
+    if (!c || !cam || W <= 0 || H <= 0 || n < 0 || (n > 0 && (!xy || !dirs))) { rtx_set_error("rtx_camera_rays: bad argument"); return RTX_E_INVALID; }
+    if (n == 0) return RTX_OK;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    DevBuf<int> dxy;
+    DevBuf<float> dd;
+    int rc;
+    if ((rc = dxy.reserve(2 * (size_t)n)) || (rc = dd.reserve(3 * (size_t)n))) { dxy.release(); dd.release(); return rc; }
+    rc = RTX_E_DEVICE;
+    if (hipMemcpy(dxy.p, xy, 2 * (size_t)n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(k_camera_rays, dim3((n + 255) / 256), dim3(256), 0, 0, make_camera(cam, W, H), n, (const int*)dxy.p, dd.p);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(dirs, dd.p, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) rc = RTX_OK;
+    }
+    if (rc) rtx_set_error("rtx_camera_rays: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+    dxy.release(); dd.release();
+    return rc;
+}
+
+}  // extern "C"
