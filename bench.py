@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (primary + shadow + reflection) on scene7 @ 3840x2160, max depth 5.
+
+One "step" is one full frame: every rank renders its interleaved row tiles of the same 4K frame
+(scene and grid replicated per GPU), then the rows are gathered to rank 0 over RCCL.  The scene, the
+grid and all queues are resident in HBM before the timed region; the timed region is K frames between
+barrier + synchronize pairs, maximum over ranks.  Total work per step is fixed, so scaling is "strong".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as rt  # noqa: E402
+from raytracer_amd.multi_gpu import FrameGather  # noqa: E402
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 128 lanes x 2 (FMA) x 2.4 GHz
+PEAK_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 4   # IEEE mul/add kept separate and unpacked: 1 flop/lane/clk
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops(w):
+    """fp32 operations of the reference algorithm for the counted work of one kernel family
+    (tri, sphere, xform, cell steps, fine steps, light evals, nearest hits, rays):
+    75 per triangle test, 31 per sphere test, 33 per ray->object transform, 50 per ray for slab test + walk
+    setup, 5 per cell step (coarse or fine), 110 per unshadowed light evaluation, 60 per nearest hit."""
+    tri, sph, xf, cells, fine, light, hits, rays = (float(v) for v in w)
+    return 75 * tri + 31 * sph + 33 * xf + 50 * rays + 5 * (cells + fine) + 110 * light + 60 * hits
+
+
+def cpu_baseline(scene_path, width, height, max_depth, row_start, row_step):
+    """Times the CPU oracle (reference-shaped port) on a bounded row subset of the same frame."""
+    from oracle import ref_oracle
+    counted = ref_oracle.RefScene(scene_path, counting=True)
+    _, _, _, cnt = counted.render(width, height, max_depth, row_start, row_step)
+    counted.close()
+    plain = ref_oracle.RefScene(scene_path, counting=False)
+    _, _, sec, _ = plain.render(width, height, max_depth, row_start, row_step)
+    plain.close()
+    rays = cnt["primary"] + cnt["shadow"] + cnt["reflect"]
+    n_rows = len(range(row_start, height, row_step))
+    return {"value": rays / sec / 1e6, "unit": "Mrays/s", "cores": ref_oracle.threads(), "kind": "port",
+            "sample": f"rows {row_start}::{row_step} ({n_rows} of {height} rows, {n_rows * width} pixels, {rays} rays) "
+                      f"of the same scene7 {width}x{height} depth-{max_depth} frame, OpenMP over rows, {sec:.2f} s",
+            "seconds": sec, "rays": rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "scene7.test"))
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--max-depth", type=int, default=5)
+    ap.add_argument("--sub", type=int, default=12, help="fine cells per coarse cell and axis of the nested grid")
+    ap.add_argument("--search", choices=["nested", "reference-lists"], default="nested")
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
+    ap.add_argument("--cpu-row-step", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU: the renderer has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, depth = args.width, args.height, args.max_depth
+    search = rt.SEARCH_NESTED if args.search == "nested" else rt.SEARCH_REFERENCE_LISTS
+    sr = rt.SceneReader().readScene(args.scene)
+    r = rt.Renderer(local_rank)
+    r.set_scene(sr)
+    gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+
+    fg = FrameGather(H, W, 3, args.tile_rows, rank, world, dev)
+    local = fg.local_view()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def frame(want_stats=False, count=False, mode=search):
+        st = r.render_device(local.data_ptr(), 0, W, H, depth, mode, args.tile_rows, rank, world, stream=stream,
+                             want_stats=want_stats, count_work=count)
+        img = fg.gather()
+        return st, img
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames)
+    st_count, _ = frame(want_stats=True, count=True)
+    kern = []
+    for _ in range(5):
+        st_t, _ = frame(want_stats=True)
+        kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
+    kern = np.median(np.array(kern), axis=0)
+    rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays],
+                              dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays_local)
+    rays = [int(v) for v in rays_local.tolist()]
+    total_rays = sum(rays)
+
+    out = None
+    if rank == 0:
+        value = total_rays / (ms_per_step * 1e-3) / 1e6
+        levels = depth + 1
+        trace_flops = algorithmic_flops(st_count.trace_work)
+        shade_flops = algorithmic_flops(st_count.shade_work)
+        trace_s = kern[1] * 1e-3
+        achieved = trace_flops / trace_s / 1e12
+        frame_bytes = 12.0 * W * H / world
+        roofline = {
+            "bound": "valu", "kernel": "k_trace (nearest hit: slab test, 3D-DDA, triangle/sphere tests), "
+                                       f"{levels} launches per frame, figures are per launch on rank 0",
+            "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+            "frac_of_unfused_peak": achieved / PEAK_UNFUSED_TFLOPS, "peak_unfused": PEAK_UNFUSED_TFLOPS,
+            "algorithmic_flops_per_launch": trace_flops / levels, "avg_launch_ms": kern[1] / levels,
+            "shade_kernel": {"achieved": shade_flops / (kern[2] * 1e-3) / 1e12, "avg_launch_ms": kern[2] / levels,
+                             "algorithmic_flops_per_launch": shade_flops / levels},
+            "hbm_algorithmic_GBs": frame_bytes / (kern[0] * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
+            "traffic": None,
+        }
+        out = {
+            "metric": "Mrays/sec (primary+shadow+reflection) on scene7 @4K", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
+            "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {depth}, 15^3 grid, search={args.search}, "
+                                   f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "
+                                   "gather to rank 0",
+                       "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays},
+                       "kernel_ms_rank0": {"frame": kern[0], "trace": kern[1], "shade": kern[2], "resolve": kern[3]},
+                       "grid": {"refs_reference_lists": gi.n_refs, "fine_cells": gi.n_fine_cells,
+                                "refs_fine": gi.n_fine_refs, "build_ms": gi.build_ms}},
+            "roofline": roofline,
+        }
+    # secondary figure: the reference's own workload (every primitive of every reference cell list tested)
+    if not args.no_reference_lists and world == 1 and search == rt.SEARCH_NESTED:
+        stc, _ = frame(want_stats=True, count=True, mode=rt.SEARCH_REFERENCE_LISTS)
+        stt, _ = frame(want_stats=True, mode=rt.SEARCH_REFERENCE_LISTS)
+        tf = algorithmic_flops(stc.trace_work)
+        out["reference_lists"] = {
+            "what": "same frame with every primitive of each visited reference cell list tested (the reference's work)",
+            "value": stc.total_rays / (stt.frame_ms * 1e-3) / 1e6, "unit": "Mrays/s", "frame_ms": stt.frame_ms,
+            "trace_ms": stt.trace_ms, "shade_ms": stt.shade_ms, "tri_tests": stc.tri_tests,
+            "trace_achieved_TFLOPs": tf / (stt.trace_ms * 1e-3) / 1e12,
+            "trace_frac_of_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+        }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.scene, W, H, depth, args.cpu_row_step // 2, args.cpu_row_step)
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

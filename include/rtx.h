@@ -157,8 +157,10 @@ typedef struct rtx_stats {
     /* rays = calls the reference would make to scene_content->intersect (src/main.cpp:57,70,82) */
     int64_t primary_rays, shadow_rays, reflection_rays;
     int64_t hits_per_level[16];
-    /* filled only with RTX_RENDER_COUNT_WORK */
+    /* filled only with RTX_RENDER_COUNT_WORK: whole frame, then split by kernel family in the order
+     * tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits, rays traced */
     int64_t tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits;
+    int64_t trace_work[8], shade_work[8];
     float   frame_ms;              /* first kernel to framebuffer complete on the device (HIP events)     */
     float   trace_ms, shade_ms, resolve_ms;   /* per kernel family, summed over levels                   */
     int32_t trace_launches, shade_launches, resolve_launches;

@@ -30,6 +30,8 @@
 #include <string>
 #include <vector>
 
+#include <omp.h>
+
 using namespace refm;
 
 namespace {
@@ -621,6 +623,9 @@ void ref_quantize(const float* rgb, long n_values, unsigned char* out) {
     for (long i = 0; i < n_values; i++) out[i] = (unsigned char)(clamp01(rgb[i]) * 255);
 }
 
+// number of OpenMP threads ref_render will use
+int ref_threads();
+
 int ref_has_counters() {
 #ifdef REF_COUNT
     return 1;
@@ -628,5 +633,7 @@ int ref_has_counters() {
     return 0;
 #endif
 }
+
+int ref_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

@@ -43,6 +43,7 @@ def _load(counting):
     lib.ref_render.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ref_quantize.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+    lib.ref_threads.restype = C.c_int
     return lib
 
 
@@ -154,3 +155,8 @@ def quantize(rgb):
     out = np.zeros(rgb.shape, np.uint8)
     _lib().ref_quantize(_p(rgb), rgb.size, _p(out))
     return out
+
+
+def threads():
+    """OpenMP threads the oracle's pixel loop will use."""
+    return int(_lib().ref_threads())

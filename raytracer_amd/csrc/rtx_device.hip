@@ -66,7 +66,7 @@ struct DevFrame {
     float* rgb;                    // [n_local_rows][W][3]
     int* ids;                      // [n_local_rows][W] or null
     int* counters;
-    unsigned long long* work;      // WorkCounters as 7 x u64 (instrumented kernels only)
+    unsigned long long* work;      // instrumented kernels only: 8 x u64 for the trace kernels, then 8 for shade
     // hit records of the level being processed (reused by every level)
     float4* hP;                    // position xyz, material index bits
     float4* hN;                    // normal xyz, primitive index bits
@@ -108,10 +108,10 @@ __device__ __forceinline__ int wave_alloc(int* counter, bool take) {
 }
 
 __device__ __forceinline__ void flush_work(const WorkCounters& wc, unsigned long long* out) {
-    const unsigned long long v[7] = {wc.tri_tests, wc.sphere_tests, wc.xform_evals, wc.cell_steps,
-                                     wc.fine_steps, wc.light_evals, wc.nearest_hits};
+    const unsigned long long v[8] = {wc.tri_tests, wc.sphere_tests, wc.xform_evals, wc.cell_steps,
+                                     wc.fine_steps, wc.light_evals, wc.nearest_hits, wc.rays};
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
+    for (int k = 0; k < 8; k++) {
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if (wave_lane() == 0 && x) atomicAdd(out + k, x);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade(DevScene sc, DevGrid g, Dev
         f.hL[i] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
         }
     }
-    if (COUNT) flush_work(wc, f.work);
+    if (COUNT) flush_work(wc, f.work + 8);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -628,7 +628,7 @@ int ensure_workspace(rtx_ctx* c, size_t pixels, int levels) {
     levels = std::max(levels, c->ws_levels);
     int rc;
     if ((rc = c->counters.reserve(CNT_TOTAL))) return rc;
-    if ((rc = c->work.reserve(8))) return rc;
+    if ((rc = c->work.reserve(16))) return rc;
     if ((rc = c->hP.reserve(pixels)) || (rc = c->hN.reserve(pixels)) || (rc = c->hD.reserve(pixels))) return rc;
     if ((rc = c->pix0.reserve(pixels))) return rc;
     for (int k = 0; k < 2; k++)
@@ -972,7 +972,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the chunk cursor balances the rest
 
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
-    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 8 * sizeof(unsigned long long), st));
+    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 16 * sizeof(unsigned long long), st));
     hipEvent_t* ev = c->ev;
     HIP_TRY(hipEventRecord(ev[0], st));
     for (int l = 0; l < levels; l++) {
@@ -1020,11 +1020,13 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         (void)hipEventElapsedTime(&stats->frame_ms, ev[0], ev[2]);
         (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
         if (count) {
-            unsigned long long w[8];
+            unsigned long long w[16];
             HIP_TRY(hipMemcpy(w, c->work.p, sizeof w, hipMemcpyDeviceToHost));
-            stats->tri_tests = (int64_t)w[0]; stats->sphere_tests = (int64_t)w[1]; stats->xform_evals = (int64_t)w[2];
-            stats->cell_steps = (int64_t)w[3]; stats->fine_steps = (int64_t)w[4]; stats->light_evals = (int64_t)w[5];
-            stats->nearest_hits = (int64_t)w[6];
+            for (int k = 0; k < 8; k++) { stats->trace_work[k] = (int64_t)w[k]; stats->shade_work[k] = (int64_t)w[8 + k]; }
+            stats->tri_tests = (int64_t)(w[0] + w[8]); stats->sphere_tests = (int64_t)(w[1] + w[9]);
+            stats->xform_evals = (int64_t)(w[2] + w[10]); stats->cell_steps = (int64_t)(w[3] + w[11]);
+            stats->fine_steps = (int64_t)(w[4] + w[12]); stats->light_evals = (int64_t)(w[5] + w[13]);
+            stats->nearest_hits = (int64_t)(w[6] + w[14]);
         }
     }
     return RTX_OK;

@@ -39,7 +39,7 @@ struct DevGrid {
 };
 
 struct WorkCounters {
-    unsigned long long tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits;
+    unsigned long long tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits, rays;
 };
 
 #define RT_KIND_TRI 0
@@ -153,6 +153,7 @@ __device__ __forceinline__ void test_prim(const DevScene& sc, int pid, f3 O, f3 
 template <int MODE, bool ANY, bool COUNT>
 __device__ bool traverse(const DevScene& sc, const DevGrid& g, f3 O, f3 D, float t_limit, float& t_hit, int& prim_hit,
                          WorkCounters& wc) {
+    if (COUNT) wc.rays++;
     // collidesWithBox (:91-138): six IEEE divides, +-inf for zero direction components
     const float txs = (g.lo.x - O.x) / D.x, txe = (g.hi.x - O.x) / D.x;
     const float tys = (g.lo.y - O.y) / D.y, tye = (g.hi.y - O.y) / D.y;

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SCENES = os.path.join(ROOT, "scenes")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name + ".test")
+
+
+@pytest.fixture(scope="session")
+def renderer():
+    """One GPU context for the whole session (GPU tests only)."""
+    import raytracer_amd as rt
+    r = rt.Renderer(0)
+    yield r
+    r.close()

@@ -1,0 +1,52 @@
+"""The C-ABI shared library loads and exports exactly the entry points include/rtx.h declares.  No GPU, no compute."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import raytracer_amd as rt
+from conftest import ROOT
+from raytracer_amd import api
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rtx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtx_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(rt.lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/rtx.h but not exported by librtx.so"
+    assert sorted(api.EXPORTED_SYMBOLS) == names, "python binding and header disagree on the entry points"
+
+
+def test_error_strings():
+    lib = api._load()
+    assert lib.rtx_strerror(0) == b"ok"
+    for code in range(-6, 0):
+        assert lib.rtx_strerror(code) not in (b"ok", b"unknown error code")
+    assert lib.rtx_strerror(-99) == b"unknown error code"
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the behaviour on a machine without a GPU")
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    with pytest.raises(rt.RtxError) as e:
+        rt.Renderer(0)
+    assert e.value.code == -3 and "no CPU path" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if os.path.basename(dirpath) == "build":
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text and "ref_cpu" not in text, f"{f} refers to the oracle"

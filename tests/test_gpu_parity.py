@@ -1,0 +1,263 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI, on a real MI355X.
+
+Bars: primary-hit primitive ids identical; 8-bit image within 1 LSB per channel on >= 99.9 % of pixels (measured: 0
+pixels differ); float framebuffer within 1e-6 absolute (measured: <= 6e-8, from the last-bit difference between the
+device's fp64-evaluated pow and the host's powf); ray counts equal; grid cell lists identical including order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import raytracer_amd as rt
+from conftest import GOLDEN, scene_path
+from oracle.ref_oracle import RefScene, quantize as ref_quantize
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_TOL = 1e-6          # absolute, on colours in [0, 1]
+MODES = [rt.SEARCH_REFERENCE_LISTS, rt.SEARCH_NESTED]
+GOLDEN_SCENES = ["scene1", "scene4-specular", "scene5", "scene6", "scene7"]
+
+
+def assert_image_parity(rgb, ids, rgb_ref, ids_ref):
+    assert np.array_equal(ids, ids_ref), f"{int((ids != ids_ref).sum())} primary hit ids differ"
+    assert np.abs(rgb - rgb_ref).max() <= FLOAT_TOL
+    d = np.abs(rt.quantize(rgb).astype(int) - ref_quantize(rgb_ref).astype(int)).max(axis=2)
+    assert (d > 1).sum() == 0, "a channel is off by more than 1 LSB"
+    assert (d > 0).mean() <= 1e-3, "more than 0.1 % of the pixels differ"
+
+
+def load(renderer, name, sub=0):
+    sr = rt.SceneReader().readScene(scene_path(name))
+    renderer.set_scene(sr)
+    return sr, renderer.build_grid(15, sub)
+
+
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_grid_build_matches_reference_lists(renderer, name):
+    sr, gi = load(renderer, name)
+    bounds, rstart, rids = RefScene(scene_path(name)).grid()
+    assert np.array_equal(np.array(list(gi.lo) + list(gi.hi), np.float32), bounds)
+    start, ids = renderer.download_grid(rt.GRID_REFERENCE)
+    assert np.array_equal(start, rstart) and np.array_equal(ids, rids)      # same cells, same order
+    fstart, fids = renderer.download_grid(rt.GRID_NESTED)
+    assert fstart[0] == 0 and fstart[-1] == len(fids) == gi.n_fine_refs and np.all(np.diff(fstart) >= 0)
+    assert gi.n_fine_cells == 15 ** 3 * gi.sub ** 3
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", GOLDEN_SCENES)
+def test_render_matches_golden(renderer, name, mode):
+    g = np.load(os.path.join(GOLDEN, f"golden_{name}.npz"))
+    load(renderer, name)
+    rgb, ids, st = renderer.render(int(g["width"]), int(g["height"]), 5, mode, count_work=True)
+    assert_image_parity(rgb, ids, g["rgb"], g["ids"])
+    cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert st.cell_steps == cnt["cell_steps"] and st.light_evals == cnt["light_evals"]
+    if mode == rt.SEARCH_REFERENCE_LISTS:
+        # the same candidates as the reference, minus the ones skipped after a shadow ray's first accepted hit
+        assert st.tri_tests <= cnt["tri_tests"] and st.sphere_tests <= cnt["sph_tests"]
+        assert st.trace_work[0] + st.trace_work[1] > 0 or cnt["tri_tests"] + cnt["sph_tests"] == 0
+
+
+@pytest.mark.parametrize("name,w,h", [("scene1", 640, 480), ("scene4-specular", 640, 480), ("scene6", 640, 480),
+                                      ("scene5", 320, 240), ("scene2", 640, 480), ("scene3", 333, 211)])
+def test_full_size_configs_match_live_oracle(renderer, name, w, h):
+    load(renderer, name)
+    rgb_ref, ids_ref, _, cnt = RefScene(scene_path(name), counting=True).render(w, h, 5)
+    for mode in MODES:
+        rgb, ids, st = renderer.render(w, h, 5, mode)
+        assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+        assert st.total_rays == cnt["primary"] + cnt["shadow"] + cnt["reflect"]
+
+
+def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
+    """BASELINE size.  Size-independent properties: both searches give the same frame bit for bit, ray counts
+    follow the hit counts; plus a row subset against the live oracle."""
+    W, H = 3840, 2160
+    sr, gi = load(renderer, "scene7", 12)
+    rgb_n, ids_n, st_n = renderer.render(W, H, 5, rt.SEARCH_NESTED)
+    rgb_r, ids_r, st_r = renderer.render(W, H, 5, rt.SEARCH_REFERENCE_LISTS)
+    assert np.array_equal(ids_n, ids_r)
+    assert np.array_equal(rgb_n.view(np.int32), rgb_r.view(np.int32))
+    hits = list(st_n.hits_per_level)[:6]
+    assert hits == list(st_r.hits_per_level)[:6] and hits[0] == int((ids_n >= 0).sum())
+    assert st_n.shadow_rays == sum(hits) and st_n.reflection_rays == sum(hits[:5]) and st_n.primary_rays == W * H
+    assert all(a >= b for a, b in zip(hits, hits[1:]))
+    ref = RefScene(scene_path("scene7"))
+    rgb_ref, ids_ref, _, _ = ref.render(W, H, 5, 1000, 160)          # rows 1000, 1160, ...: through the dragon
+    rows = np.arange(1000, H, 160)
+    assert_image_parity(rgb_n[rows], ids_n[rows], rgb_ref[rows], ids_ref[rows])
+    assert (ids_ref[rows] >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3])
+def test_max_depth(renderer, depth):
+    load(renderer, "scene6")
+    rgb_ref, ids_ref, _, cnt = RefScene(scene_path("scene6"), counting=True).render(96, 72, depth)
+    rgb, ids, st = renderer.render(96, 72, depth, rt.SEARCH_NESTED)
+    assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+    assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    if depth == 0:
+        assert st.reflection_rays == 0
+
+
+@pytest.mark.parametrize("w,h", [(37, 23), (1, 1), (8, 8), (9, 65), (641, 3)])
+def test_ragged_image_sizes(renderer, w, h):
+    load(renderer, "scene4-specular")
+    rgb_ref, ids_ref, _, _ = RefScene(scene_path("scene4-specular")).render(w, h, 5)
+    for mode in MODES:
+        rgb, ids, _ = renderer.render(w, h, 5, mode)
+        assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+
+
+def test_camera_rays_bit_exact(renderer):
+    load(renderer, "scene1")
+    ref = RefScene(scene_path("scene1"))
+    for (w, h) in [(640, 480), (3840, 2160), (37, 23)]:
+        rng = np.random.default_rng(w)
+        xy = np.stack([rng.integers(0, w, 300), rng.integers(0, h, 300)], axis=1).astype(np.int32)
+        xy[:4] = [[0, 0], [w - 1, 0], [0, h - 1], [w - 1, h - 1]]
+        got = renderer.camera_rays(w, h, xy)
+        want = np.stack([ref.camera_ray(w, h, int(x), int(y)) for x, y in xy])
+        assert np.array_equal(got.view(np.int32), want.view(np.int32))
+
+
+def random_rays(rng, gi, n):
+    lo, hi = np.array(gi.lo), np.array(gi.hi)
+    ext = hi - lo
+    O = (lo - ext + rng.random((n, 3)) * 3 * ext).astype(np.float32)          # inside and outside the grid
+    T = (lo + rng.random((n, 3)) * ext).astype(np.float32)
+    D = T - O
+    D /= np.linalg.norm(D, axis=1, keepdims=True)
+    D = D.astype(np.float32)
+    k = n // 8
+    D[:k, 0] = 0.0                       # axis-parallel components: the walk's infinite-crossing branches
+    D[k:2 * k, 1] = -0.0                 # negative zero: never '< 0', the reference misses the grid
+    D[2 * k:3 * k] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, k)] * rng.choice([-1, 1], (k, 1)).astype(np.float32)
+    tl = np.full(n, np.finfo(np.float32).max, np.float32)
+    tl[::3] = (rng.random(len(tl[::3])) * 2 * np.linalg.norm(ext)).astype(np.float32)
+    return O, D, tl
+
+
+@pytest.mark.parametrize("name", ["scene4-specular", "scene5", "scene6", "scene7"])
+def test_single_rays_match_oracle(renderer, name):
+    """Grid::intersect for arbitrary rays: t, primitive, position and normal bit for bit."""
+    sr, gi = load(renderer, name)
+    ref = RefScene(scene_path(name))
+    n = 600 if name in ("scene7", "scene5") else 3000
+    O, D, tl = random_rays(np.random.default_rng(11), gi, n)
+    want = [ref.intersect(O[i], D[i], float(tl[i])) for i in range(n)]
+    assert sum(w["ok"] for w in want) > n // 20
+    for mode in MODES:
+        t, prim, pos, nrm = renderer.intersect(O, D, tl, mode)
+        for i, w in enumerate(want):
+            assert (prim[i] >= 0) == w["ok"], i
+            if w["ok"]:
+                assert prim[i] == w["prim"] and t[i] == w["t"], i
+                assert np.array_equal(pos[i].view(np.int32), w["p"].view(np.int32)), i
+                assert np.array_equal(nrm[i].view(np.int32), w["n"].view(np.int32)), i
+
+
+def test_empty_scene_and_scene_without_lights(renderer):
+    sr = rt.SceneReader().parse("size 16 8\ncamera 0 0 5 0 0 0 0 1 0 45\npoint 0 5 5 1 1 1\n")
+    renderer.set_scene(sr)
+    renderer.build_grid(15, 0)
+    for mode in MODES:
+        rgb, ids, st = renderer.render(search=mode)
+        assert rgb.shape == (8, 16, 3) and not rgb.any() and (ids == -1).all()
+        assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (128, 0, 0)
+    load(renderer, "scene2")        # ambient only: no lights at all
+    rgb, ids, st = renderer.render(80, 60)
+    assert st.shadow_rays == 0 and st.reflection_rays > 0 and rgb.any()
+
+
+def test_coincident_triangles_keep_file_order(renderer):
+    sr = rt.SceneReader().parse("size 8 8\ncamera 0.25 0.25 3 0.25 0.25 0 0 1 0 20\nambient .2 .3 .4\n"
+                                "vertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\ntri 0 1 2\nambient .9 .9 .9\ntri 0 1 2\n")
+    renderer.set_scene(sr)
+    renderer.build_grid(15, 3)
+    for mode in MODES:
+        t, prim, _, _ = renderer.intersect([[0.25, 0.25, 1]], [[0, 0, -1]], None, mode)
+        assert prim[0] == 0 and t[0] == 1.0
+
+
+@pytest.mark.parametrize("world,tile_rows", [(2, 8), (3, 8), (8, 8), (4, 5)])
+def test_row_tiles_reassemble_to_the_single_gpu_frame(renderer, world, tile_rows):
+    """Tiling must not change a single bit: every rank's rows, rendered separately, equal the one-rank frame."""
+    load(renderer, "scene6")
+    W, H = 200, 117
+    full, full_ids, st_full = renderer.render(W, H, 5, rt.SEARCH_NESTED)
+    acc = np.full_like(full, np.nan)
+    acc_ids = np.full_like(full_ids, -7)
+    total = 0
+    for rank in range(world):
+        rows = rt.local_rows(H, tile_rows, rank, world)
+        rgb, ids, st = renderer.render(W, H, 5, rt.SEARCH_NESTED, tile_rows, rank, world)
+        acc[rows] = rgb[rows]
+        acc_ids[rows] = ids[rows]
+        total += st.total_rays
+        other = np.setdiff1d(np.arange(H), rows)
+        assert not rgb[other].any() and (ids[other] == -2).all()        # rows of other ranks are left untouched
+    assert np.array_equal(acc.view(np.int32), full.view(np.int32)) and np.array_equal(acc_ids, full_ids)
+    assert total == st_full.total_rays
+
+
+def test_render_device_on_a_side_stream_with_torch_memory(renderer):
+    load(renderer, "scene4-specular")
+    W, H = 160, 120
+    want, want_ids, _ = renderer.render(W, H)
+    d_rgb = torch.full((H, W, 3), -1.0, device="cuda")
+    d_ids = torch.full((H, W), -9, dtype=torch.int32, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        renderer.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, stream=s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(d_rgb.cpu().numpy().view(np.int32), want.view(np.int32))
+    assert np.array_equal(d_ids.cpu().numpy(), want_ids)
+    # twice in a row: identical bytes (every pixel is a pure function of the scene)
+    again, _, _ = renderer.render(W, H)
+    assert np.array_equal(again.view(np.int32), want.view(np.int32))
+
+
+def test_state_and_argument_errors():
+    r = rt.Renderer(0)
+    try:
+        sr = rt.SceneReader().readScene(scene_path("scene1"))
+        r.scene = sr
+        with pytest.raises(rt.RtxError) as e:
+            r.render(8, 8)
+        assert e.value.code == -4                       # no scene uploaded
+        r.set_scene(sr)
+        with pytest.raises(rt.RtxError) as e:
+            r.render(8, 8)
+        assert e.value.code == -4                       # no grid built
+        r.build_grid(15, 0, rt.GRID_REFERENCE)
+        with pytest.raises(rt.RtxError) as e:
+            r.render(8, 8, search=rt.SEARCH_NESTED)
+        assert e.value.code == -4                       # nested grid was not requested
+        r.render(8, 8, search=rt.SEARCH_REFERENCE_LISTS)
+        with pytest.raises(rt.RtxError) as e:
+            r.render(8, 8, max_depth=16, search=rt.SEARCH_REFERENCE_LISTS)
+        assert e.value.code == -6
+        with pytest.raises(rt.RtxError) as e:
+            r.build_grid(0, 0)
+        assert e.value.code == -1
+        bad = rt.SceneReader().readScene(scene_path("scene1"))
+        bad.prim_xform = bad.prim_xform + 5
+        with pytest.raises(rt.RtxError) as e:
+            r.set_scene(bad)
+        assert e.value.code == -1
+    finally:
+        r.close()
+
+
+def test_general_grid_resolution(renderer):
+    """Resolutions other than the reference's 15^3 keep the nearest-hit semantics: same ids as 15^3."""
+    load(renderer, "scene4-specular")
+    base, base_ids, _ = renderer.render(160, 120)
+    renderer.build_grid((9, 20, 5), 2)
+    rgb, ids, _ = renderer.render(160, 120)
+    assert (ids != base_ids).mean() < 1e-3
