@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
-    ap.add_argument("--cpu-row-step", type=int, default=32)
+    ap.add_argument("--cpu-row-step", type=int, default=8)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
