@@ -122,14 +122,16 @@ typedef struct rtx_grid_info {
     float   lo[3], hi[3];          /* Grid::start_pos / end_pos (src/grid.h:12-13)                 */
     int32_t rx, ry, rz, sub;
     int64_t n_cells, n_refs;       /* coarse cells, references in the reference lists (0 if not built) */
-    int64_t n_fine_cells, n_fine_refs;
+    int64_t n_fine_cells, n_fine_refs;   /* fine cells incl. padding (32 * ceil(sub^3 / 32) per coarse cell) */
+    int64_t n_occupied_fine_cells;
     float   build_ms;              /* GPU time of the last rtx_build_grid                           */
 } rtx_grid_info;
 int  rtx_get_grid_info(const rtx_ctx* ctx, rtx_grid_info* out);
 /* Copies a grid's CSR arrays to the host.  which = RTX_GRID_REFERENCE or RTX_GRID_NESTED.
- * cell_start has n_cells+1 (n_fine_cells+1) entries, prim_ids n_refs (n_fine_refs).  Cell (x,y,z) is
- * entry x + rx*y + rx*ry*z (Grid::getOffsetAtIndices, src/grid.h:61-63).  Within a cell the ids are
- * ascending, i.e. in file order as in the reference (src/grid.h:46-48,65-68). */
+ * cell_start has n_cells+1 (n_fine_cells+1) entries, prim_ids n_refs (n_fine_refs).  Coarse cell (x,y,z) is
+ * entry x + rx*y + rx*ry*z (Grid::getOffsetAtIndices, src/grid.h:61-63); fine cell (lx,ly,lz) of coarse cell c
+ * is entry c * (n_fine_cells / n_cells) + lx + sub*(ly + sub*lz).  Within a cell the ids are ascending, i.e. in
+ * file order as in the reference (src/grid.h:46-48,65-68). */
 int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, int32_t* prim_ids);
 
 /* How the primitives of one coarse cell are searched (Container::intersect, src/geometries.h:173-204):
@@ -142,6 +144,11 @@ int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, 
 #define RTX_SEARCH_NESTED          1
 
 #define RTX_RENDER_COUNT_WORK 1u   /* run the instrumented kernels and fill the work counters of rtx_stats */
+#define RTX_RENDER_LEVEL_QUEUES 4u /* level-synchronous pipeline: global ray / hit queues in device memory, one
+                                      trace and one shade launch per recursion level, then resolve launches;
+                                      default is one persistent launch per frame (per-wave path pools)        */
+#define RTX_RENDER_SERIAL_LANES 2u /* one lane walks and tests its own ray alone (no sharing of candidate tests
+                                      across the wave); same results, kept for A/B timing                     */
 
 typedef struct rtx_render_params {
     int32_t  width, height;        /* full image; y = 0 is the top row (src/main.cpp:127-131)           */
@@ -161,8 +168,12 @@ typedef struct rtx_stats {
      * tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits, rays traced */
     int64_t tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits;
     int64_t trace_work[8], shade_work[8];
+    int64_t wave_events[4];        /* wave-cooperative kernels: rounds, walk-loop iterations, 64-pair test batches,
+                                      state updates -- each counted once per wave                               */
     float   frame_ms;              /* first kernel to framebuffer complete on the device (HIP events)     */
-    float   trace_ms, shade_ms, resolve_ms;   /* per kernel family, summed over levels                   */
+    float   trace_ms, shade_ms, resolve_ms;   /* per kernel family, summed over levels; the persistent frame
+                                                 kernel is reported as trace_ms with trace_launches = 1   */
+    float   level_trace_ms[16], level_shade_ms[16];   /* the same per level                              */
     int32_t trace_launches, shade_launches, resolve_launches;
 } rtx_stats;
 

@@ -18,6 +18,8 @@ SEARCH_NESTED = 1
 GRID_REFERENCE = 1
 GRID_NESTED = 2
 RENDER_COUNT_WORK = 1
+RENDER_SERIAL_LANES = 2
+RENDER_LEVEL_QUEUES = 4
 
 
 class RtxError(RuntimeError):
@@ -40,7 +42,7 @@ class _Camera(C.Structure):
 class GridInfo(C.Structure):
     _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3), ("rx", C.c_int32), ("ry", C.c_int32), ("rz", C.c_int32),
                 ("sub", C.c_int32), ("n_cells", C.c_int64), ("n_refs", C.c_int64), ("n_fine_cells", C.c_int64),
-                ("n_fine_refs", C.c_int64), ("build_ms", C.c_float)]
+                ("n_fine_refs", C.c_int64), ("n_occupied_fine_cells", C.c_int64), ("build_ms", C.c_float)]
 
 
 class _RenderParams(C.Structure):
@@ -55,8 +57,9 @@ class RenderStats(C.Structure):
                 ("tri_tests", C.c_int64), ("sphere_tests", C.c_int64), ("xform_evals", C.c_int64),
                 ("cell_steps", C.c_int64), ("fine_steps", C.c_int64), ("light_evals", C.c_int64),
                 ("nearest_hits", C.c_int64),
-                ("trace_work", C.c_int64 * 8), ("shade_work", C.c_int64 * 8),
+                ("trace_work", C.c_int64 * 8), ("shade_work", C.c_int64 * 8), ("wave_events", C.c_int64 * 4),
                 ("frame_ms", C.c_float), ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("resolve_ms", C.c_float),
+                ("level_trace_ms", C.c_float * 16), ("level_shade_ms", C.c_float * 16),
                 ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("resolve_launches", C.c_int32)]
 
     @property
@@ -64,7 +67,7 @@ class RenderStats(C.Structure):
         return self.primary_rays + self.shadow_rays + self.reflection_rays
 
     def as_dict(self):
-        arrays = ("hits_per_level", "trace_work", "shade_work")
+        arrays = ("hits_per_level", "trace_work", "shade_work", "wave_events", "level_trace_ms", "level_shade_ms")
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in arrays}
         for k in arrays:
             d[k] = list(getattr(self, k))
@@ -73,7 +76,7 @@ class RenderStats(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "librtx.so")
+    return os.environ.get("RTX_LIB_PATH") or os.path.join(_HERE, "librtx.so")
 
 
 _lib = None
@@ -290,13 +293,15 @@ class Renderer:
         return start, ids[:n_refs]
 
     def render(self, width=0, height=0, max_depth=5, search=SEARCH_NESTED, tile_rows=8, rank=0, world=1,
-               want_ids=True, count_work=False, camera=None, eps_bias=SceneReader.epsilonBias):
+               want_ids=True, count_work=False, camera=None, eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False):
         """Renders this rank's rows into full-size host arrays.  Returns (rgb[H,W,3], ids[H,W] or None, stats)."""
         sc = self.scene
         W = width if width > 0 else sc.width
         H = height if height > 0 else sc.height
         cam = camera if camera is not None else sc._camera()
-        p = _params(W, H, max_depth, eps_bias, search, tile_rows, rank, world, RENDER_COUNT_WORK if count_work else 0)
+        flags = ((RENDER_COUNT_WORK if count_work else 0) | (RENDER_SERIAL_LANES if serial_lanes else 0) |
+                 (RENDER_LEVEL_QUEUES if level_queues else 0))
+        p = _params(W, H, max_depth, eps_bias, search, tile_rows, rank, world, flags)
         rgb = np.zeros((H, W, 3), np.float32)
         ids = np.full((H, W), -2, np.int32) if want_ids else None
         st = RenderStats()
@@ -305,11 +310,12 @@ class Renderer:
 
     def render_device(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8,
                       rank=0, world=1, stream=None, want_stats=False, count_work=False, camera=None,
-                      eps_bias=SceneReader.epsilonBias):
+                      eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False):
         """Enqueues one frame writing DEVICE memory (raw pointers, e.g. torch tensor data_ptr())."""
         cam = camera if camera is not None else self.scene._camera()
-        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world,
-                    RENDER_COUNT_WORK if count_work else 0)
+        flags = ((RENDER_COUNT_WORK if count_work else 0) | (RENDER_SERIAL_LANES if serial_lanes else 0) |
+                 (RENDER_LEVEL_QUEUES if level_queues else 0))
+        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags)
         st = RenderStats() if want_stats else None
         _check(_load().rtx_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_rgb_ptr),
                                          C.c_void_p(d_ids_ptr) if d_ids_ptr else None,

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -23,11 +24,15 @@
 #include "rt_math.h"
 #include "rt_xform.h"
 #include "rtx_traverse.h"
+#include "rtx_wave.h"
 
 using namespace rt;
 
 #define RTX_MAX_LEVELS 16          // max_depth <= 15
 #define RTX_BLOCK 256
+#ifndef RTX_FRAME_WAVES_PER_SIMD
+#define RTX_FRAME_WAVES_PER_SIMD 3      // occupancy the persistent kernel's register allocation is held to
+#endif
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -62,6 +67,8 @@ struct DevFrame {
     int n_items0;                  // level-0 work items (8x8 pixel blocks * 64)
     int max_depth;
     float bias;
+    int walk_budget;               // persistent kernel: walk steps a lane may take per round
+    int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
     DevCamera cam;
     float* rgb;                    // [n_local_rows][W][3]
     int* ids;                      // [n_local_rows][W] or null
@@ -115,6 +122,15 @@ __device__ __forceinline__ void flush_work(const WorkCounters& wc, unsigned long
         unsigned long long x = v[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
         if (wave_lane() == 0 && x) atomicAdd(out + k, x);
+    }
+    // wave-level events are incremented by every lane that was active at the time: the maximum over the lanes
+    // is the number of times the wave went through that point
+    const unsigned long long e[4] = {wc.w_rounds, wc.w_walk_iters, wc.w_test_batches, wc.w_updates};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = e[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+        if (wave_lane() == 0 && x) atomicAdd(out + 16 + k, x);
     }
 }
 
@@ -198,9 +214,38 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, DevGrid g, Dev
     if (COUNT) flush_work(wc, f.work);
 }
 
-// pow(max(x, 0), shininess) as the reference's host libm evaluates it: computed in fp64 and rounded once,
-// which agrees with a correctly rounded fp32 powf except in vanishingly rare double-rounding cases.
-__device__ __forceinline__ float pow_shine(float x, float y) { return (float)pow((double)x, (double)y); }
+// pow(x, y) for the Blinn-Phong term (src/main.cpp:41), x = max(clamp(N.H), 0) in [0, 1] (or NaN), y = shininess.
+// The reference's host libm returns the correctly rounded fp32 power in all but vanishingly rare cases; this
+// evaluates exp2(y * log2(x)) in fp64 (atanh series for the logarithm, Taylor series for the exponential, both to
+// below 1e-16) and rounds once to fp32, which agrees with that except when the exact value lies within ~1e-13
+// relative of a rounding boundary.  Written out by hand because the general library pow needs ~40 more VGPRs.
+__device__ __forceinline__ float pow_shine(float x, float y) {
+    if (y == 0.0f || x == 1.0f) return 1.0f;
+    if (x != x || y != y) return x + y;                        // NaN in, NaN out
+    if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+    if (__builtin_isinf(y)) return y > 0.0f ? 0.0f : __builtin_inff();   // 0 < x < 1 here
+    const long long bits = __double_as_longlong((double)x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;        // ln m = 2 atanh(s), |s| <= 0.1716
+    double p = 1.0 / 23.0;
+    p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0); p = fma(p, s2, 1.0);
+    const double log2x = fma(2.0 * s * p, 1.4426950408889634, (double)e);
+    const double z = (double)y * log2x;
+    if (z < -160.0) return 0.0f;
+    if (z > 130.0) return __builtin_inff();
+    const double n = rint(z), t = (z - n) * 0.6931471805599453;   // |t| <= 0.3466
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, t, 1.0 / 479001600.0); q = fma(q, t, 1.0 / 39916800.0); q = fma(q, t, 1.0 / 3628800.0);
+    q = fma(q, t, 1.0 / 362880.0); q = fma(q, t, 1.0 / 40320.0); q = fma(q, t, 1.0 / 5040.0); q = fma(q, t, 1.0 / 720.0);
+    q = fma(q, t, 1.0 / 120.0); q = fma(q, t, 1.0 / 24.0); q = fma(q, t, 1.0 / 6.0); q = fma(q, t, 0.5);
+    q = fma(q, t, 1.0); q = fma(q, t, 1.0);
+    const double scale = __longlong_as_double((long long)((int)n + 1023) << 52);
+    return (float)(q * scale);
+}
 
 // calc_lighting (src/main.cpp:30-45)
 __device__ __forceinline__ f3 light_term(f3 rayDir, f3 L, f3 N, f3 kd, f3 ks, float shininess, f3 lc) {
@@ -293,6 +338,282 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_resolve(DevScene sc, DevFrame f, 
             f.hL[i] = make_float4(C.x, C.y, C.z, l4.w);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wave-cooperative variants (rtx_wave.h): same queues, same records, same arithmetic; the 64 lanes of a wave
+// share the candidate tests of their 64 rays
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool SINGLE_XF, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, int level) {
+    __shared__ WaveLds lds[RTX_BLOCK / 64];
+    WaveLds& l = lds[threadIdx.x >> 6];
+    WorkCounters wc = {};
+    const int lane = wave_lane();
+    const int n = (level == 0) ? f.n_items0 : f.counters[CNT_HITS + level - 1];
+    for (;;) {
+        const int base = next_chunk(f.counters + CNT_TRACE_CUR + level);
+        if (base >= n) break;
+        const int i = base + lane;
+        bool active = i < n;
+        f3 O = mk(0, 0, 0), D = mk(0, 0, 1);
+        int pix = -1;
+        if (level == 0) {
+            const int blk = i >> 6, in = i & 63;
+            const int lr = 8 * (blk / f.nbx) + (in >> 3);
+            const int x = 8 * (blk % f.nbx) + (in & 7);
+            active = active && lr < f.n_local_rows && x < f.W;
+            if (active) {
+                const int tile = lr / f.tile_rows;
+                const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+                pix = lr * f.W + x;
+                O = f.cam.eye;
+                D = camera_ray(f.cam, x, y);
+            }
+        } else if (active) {
+            const float4 o = f.rO_in[i], d = f.rD_in[i];
+            O = mk(o.x, o.y, o.z);
+            D = mk(d.x, d.y, d.z);
+        }
+        const f3 Dn = normalize3(D);
+        float t = 0;
+        int prim = -1;
+        const bool hit = trace_wave<MODE, false, SINGLE_XF, COUNT>(sc, g, sp, l, O, Dn, FLT_MAX, active, t, prim, wc);
+        const int slot = wave_alloc(f.counters + CNT_HITS + level, hit);
+        if (hit) {
+            if (COUNT) wc.nearest_hits++;
+            f3 P, N;
+            int material;
+            finish_hit(sc, prim, O, Dn, t, P, N, material);
+            f.hP[slot] = make_float4(P.x, P.y, P.z, as_float(material));
+            f.hN[slot] = make_float4(N.x, N.y, N.z, as_float(prim));
+            f.hD[slot] = make_float4(D.x, D.y, D.z, 0.0f);
+            f.hChild[slot] = -1;
+            if (level == 0) {
+                f.pix0[slot] = pix;
+                if (f.ids) f.ids[pix] = prim;
+            } else {
+                f.hChild_prev[i] = slot;
+            }
+            if (level < f.max_depth) {
+                const f3 V = normalize3(-D);
+                const f3 R = (2.0f * dot3(V, N) * N) - V;
+                const f3 Po = P + f.bias * R;
+                f.rO_out[slot] = make_float4(Po.x, Po.y, Po.z, 0.0f);
+                f.rD_out[slot] = make_float4(R.x, R.y, R.z, 0.0f);
+            }
+        } else if (level == 0 && active) {
+            f.rgb[3 * pix] = 0.0f;
+            f.rgb[3 * pix + 1] = 0.0f;
+            f.rgb[3 * pix + 2] = 0.0f;
+            if (f.ids) f.ids[pix] = -1;
+        }
+    }
+    if (COUNT) flush_work(wc, f.work);
+}
+
+template <int MODE, bool SINGLE_XF, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, int level) {
+    __shared__ WaveLds lds[RTX_BLOCK / 64];
+    WaveLds& l = lds[threadIdx.x >> 6];
+    WorkCounters wc = {};
+    const int lane = wave_lane();
+    const int n = f.counters[CNT_HITS + level];
+    for (;;) {
+        const int base = next_chunk(f.counters + CNT_SHADE_CUR + level);
+        if (base >= n) break;
+        const int i = base + lane;
+        const bool active = i < n;
+        const int ii = active ? i : 0;
+        const float4 p4 = f.hP[ii], n4 = f.hN[ii], d4 = f.hD[ii];
+        const f3 P = mk(p4.x, p4.y, p4.z), N = mk(n4.x, n4.y, n4.z), rayDir = mk(d4.x, d4.y, d4.z);
+        const int material = as_int(p4.w);
+        const float* m = sc.mats + 16 * material;
+        const f3 ka = mk(m[0], m[1], m[2]), kd = mk(m[3], m[4], m[5]), ks = mk(m[6], m[7], m[8]), ke = mk(m[9], m[10], m[11]);
+        const float shininess = m[12];
+        f3 acc = mk(0, 0, 0);
+        for (int li = 0; li < sc.n_lights; li++) {          // wave-uniform loop
+            const float* lt = sc.lights + 12 * li;
+            const f3 lpos = mk(lt[1], lt[2], lt[3]), lcol = mk(lt[4], lt[5], lt[6]);
+            const bool point = (int)lt[0] == RTX_LIGHT_POINT;
+            const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
+            const f3 So = P + f.bias * L;
+            const float tL = point ? dot3(lpos - P, L) : FLT_MAX;
+            float t;
+            int prim;
+            const bool occluded = trace_wave<MODE, true, SINGLE_XF, COUNT>(sc, g, sp, l, So, L, tL, active, t, prim, wc);
+            if (active && !occluded) {
+                if (COUNT) wc.light_evals++;
+                const f3 c = light_term(rayDir, L, N, kd, ks, shininess, lcol);
+                if (point) {
+                    const float att = lt[7] + lt[8] * tL + lt[9] * tL * tL;
+                    acc = acc + c / att;
+                } else {
+                    acc = acc + c;
+                }
+            }
+        }
+        if (active) {
+            const f3 sh = clamp_rgb(acc);
+            const f3 Lsum = ka + ke + sh;
+            f.hL[i] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+        }
+    }
+    if (COUNT) flush_work(wc, f.work + 8);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// persistent frame kernel: one launch per frame, every wave keeps a pool of 64 paths alive
+//
+// The level-synchronous kernels above wait at every level for the slowest ray of that level.  Here a wave
+// never waits for another wave: each lane carries one pixel's path through its states (nearest-hit ray of
+// level d -> one shadow ray per light -> mirror ray of level d+1 ...), all 64 lanes share the candidate tests
+// of whatever rays they hold (wave_round), and a lane whose path has ended draws the next pixel from a
+// global cursor.  A path's per-level terms L_d live in a private strip of global memory until the path ends
+// and is folded from its deepest level up (the return path of trace(), src/main.cpp:99-102).
+// Results are bit-identical to the level-synchronous kernels: every ray and every term is computed by the
+// same code, only the schedule differs.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, bool SINGLE_XF, bool COUNT>
+__global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
+    __shared__ WaveLds lds[RTX_BLOCK / 64];
+    __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+    const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
+    WaveLds& l = lds[wave];
+    if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
+    float4* stack = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
+    WorkCounters wc = {};
+
+    // path state of this lane
+    int pix = -1, level = 0, phase = 0, material = 0;   // phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i
+    f3 O = mk(0, 0, 0), D = mk(0, 0, 1), rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
+    float tl = FLT_MAX;
+    Walker<MODE> w;
+    LaneSearch r;
+    w.init(g, O, D, tl, false);
+    r.Or = O; r.Dr = D; r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
+    bool exhausted = false;
+
+    for (;;) {
+        const bool walking = pix >= 0 && w.state != 2;
+        const bool finished = pix >= 0 && w.state == 2;
+        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(pix < 0)));
+        if (!__any(walking) || n_ready >= f.ready_threshold) {
+            if (COUNT) wc.w_updates++;
+            bool begin = false;
+            if (finished) {
+                bool path_end = false, lit = false;
+                int top = -1, next_light = -1;
+                if (phase == 0) {
+                    if (!w.hit) {                              // src/main.cpp:104-106
+                        path_end = true;
+                        top = level - 1;
+                        if (level == 0 && f.ids) f.ids[pix] = -1;
+                    } else {
+                        if (COUNT) wc.nearest_hits++;
+                        const int prim = r.best_prim;
+                        finish_hit(sc, prim, O, D, r.best_t, P, N, material);
+                        atomicAdd(&hit_count[wave][level], 1);
+                        if (level == 0 && f.ids) f.ids[pix] = prim;
+                        acc = mk(0, 0, 0);
+                        if (sc.n_lights > 0) next_light = 0; else lit = true;
+                    }
+                } else {                                        // src/main.cpp:57-75
+                    const int li = phase - 1;
+                    if (!w.hit) {
+                        const float* lt = sc.lights + 12 * li;
+                        const float* m = sc.mats + 16 * material;
+                        if (COUNT) wc.light_evals++;
+                        const f3 c = light_term(rayDir, D, N, mk(m[3], m[4], m[5]), mk(m[6], m[7], m[8]), m[12], mk(lt[4], lt[5], lt[6]));
+                        if ((int)lt[0] == RTX_LIGHT_POINT) {
+                            const float att = lt[7] + lt[8] * tl + lt[9] * tl * tl;
+                            acc = acc + c / att;
+                        } else {
+                            acc = acc + c;
+                        }
+                    }
+                    if (li + 1 < sc.n_lights) next_light = li + 1; else lit = true;
+                }
+                if (lit) {                                      // src/main.cpp:85-102
+                    const float* m = sc.mats + 16 * material;
+                    const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
+                    stack[level] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                    if (level < f.max_depth) {
+                        const f3 V = normalize3(-rayDir);
+                        const f3 R = (2.0f * dot3(V, N) * N) - V;
+                        O = P + f.bias * R;
+                        rayDir = R;
+                        D = normalize3(R);
+                        tl = FLT_MAX;
+                        level++;
+                        phase = 0;
+                        begin = true;
+                    } else {
+                        path_end = true;
+                        top = level;
+                    }
+                }
+                if (next_light >= 0) {
+                    const float* lt = sc.lights + 12 * next_light;
+                    const f3 lpos = mk(lt[1], lt[2], lt[3]);
+                    const bool point = (int)lt[0] == RTX_LIGHT_POINT;
+                    const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
+                    O = P + f.bias * L;
+                    D = L;
+                    tl = point ? dot3(lpos - P, L) : FLT_MAX;
+                    phase = 1 + next_light;
+                    begin = true;
+                }
+                if (path_end) {
+                    f3 C = mk(0, 0, 0);
+                    for (int d = top; d >= 0; d--) {
+                        const float4 s4 = stack[d];
+                        const float* m = sc.mats + 16 * as_int(s4.w);
+                        C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
+                    }
+                    f.rgb[3 * pix] = C.x;
+                    f.rgb[3 * pix + 1] = C.y;
+                    f.rgb[3 * pix + 2] = C.z;
+                    pix = -1;
+                }
+            }
+            // lanes without a path draw the next pixels
+            const bool idle = pix < 0;
+            const unsigned long long idle_mask = __ballot(idle);
+            if (!exhausted && idle_mask != 0) {
+                const int n_idle = __popcll(idle_mask);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(f.counters + CNT_TRACE_CUR, n_idle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (idle) {
+                    const int i = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                    if (i < f.n_items0) {
+                        const int blk = i >> 6, in = i & 63;
+                        const int lr = 8 * (blk / f.nbx) + (in >> 3);
+                        const int x = 8 * (blk % f.nbx) + (in & 7);
+                        if (lr < f.n_local_rows && x < f.W) {
+                            const int tile = lr / f.tile_rows;
+                            const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+                            pix = lr * f.W + x;
+                            O = f.cam.eye;
+                            rayDir = camera_ray(f.cam, x, y);
+                            D = normalize3(rayDir);             // src/main.cpp:82
+                            tl = FLT_MAX;
+                            level = 0;
+                            phase = 0;
+                            begin = true;
+                        }
+                    }
+                }
+                if (base + n_idle >= f.n_items0) exhausted = true;
+            }
+            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
+            if (exhausted && !__any(pix >= 0)) break;
+        }
+        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, l, w, r, phase != 0, f.walk_budget, wc);
+    }
+    if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
+    if (COUNT) flush_work(wc, f.work);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -400,6 +721,7 @@ struct BinParams {
     f3 lo, size, res;              // getCellIndicesAtPosition operands (src/grid.h:53-59)
     int rx, ry, rz;
     float pad;                     // box growth (0 for the reference lists)
+    int sub, cpb;                  // sub > 0: block-major numbering, cell = coarse * cpb + local (nested grid)
 };
 
 // Inclusive cell range of one box: clamp(floor((p - lo) * res / size), 0, res - 1) per corner and axis
@@ -423,7 +745,14 @@ __global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cur
     for (int z = c0[2]; z <= c1[2]; z++)
         for (int y = c0[1]; y <= c1[1]; y++)
             for (int x = c0[0]; x <= c1[0]; x++) {
-                const int cell = x + bp.rx * (y + bp.ry * z);
+                int cell;
+                if (bp.sub > 0) {
+                    const int cx = x / bp.sub, cy = y / bp.sub, cz = z / bp.sub;
+                    const int coarse = cx + (bp.rx / bp.sub) * (cy + (bp.ry / bp.sub) * cz);
+                    cell = coarse * bp.cpb + (x - cx * bp.sub) + bp.sub * ((y - cy * bp.sub) + bp.sub * (z - cz * bp.sub));
+                } else {
+                    cell = x + bp.rx * (y + bp.ry * z);
+                }
                 const int k = atomicAdd(count_or_cursor + cell, 1);
                 if (FILL) ids[start[cell] + k] = i;
             }
@@ -486,19 +815,33 @@ __global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* star
     }
 }
 
-// coarse-cell occupancy of the nested grid
-__global__ void k_occupancy(int rx, int ry, int rz, int sub, const int* fstart, unsigned char* occ) {
+// Sparse view of the nested grid, step 1: occupancy mask of every 32 fine cells and its population count
+__global__ void k_words(int n_words, const int* fstart, unsigned* mask, int* pop) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= n_words) return;
+    unsigned m = 0;
+    for (int b = 0; b < 32; b++) m |= (fstart[32 * w + b + 1] > fstart[32 * w + b]) ? (1u << b) : 0u;
+    mask[w] = m;
+    pop[w] = __popc(m);
+}
+// step 2 (after the prefix sum of pop): (mask, occupied cells before the word) pairs and the compact CSR starts
+__global__ void k_compact(int n_words, const int* fstart, const unsigned* mask, const int* wpre, uint2* words, int* ostart) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= n_words) return;
+    const unsigned m = mask[w];
+    int o = wpre[w];
+    words[w] = make_uint2(m, (unsigned)o);
+    for (int b = 0; b < 32; b++)
+        if (m & (1u << b)) ostart[o++] = fstart[32 * w + b];
+    if (w == n_words - 1) ostart[wpre[n_words]] = fstart[32 * n_words];
+}
+// coarse-cell occupancy of the nested grid: any fine cell of the block holds a primitive
+__global__ void k_occupancy(int n_blocks, int words_per_block, const unsigned* mask, unsigned char* occ) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (c >= rx * ry * rz) return;
-    const int ix = c % rx, iy = (c / rx) % ry, iz = c / (rx * ry);
-    const int frx = rx * sub, fry = ry * sub;
-    int any = 0;
-    for (int z = 0; z < sub && !any; z++)
-        for (int y = 0; y < sub && !any; y++) {
-            const int row = (ix * sub) + frx * ((iy * sub + y) + fry * (iz * sub + z));
-            any = fstart[row + sub] > fstart[row];   // lists of one x-run are contiguous in the CSR
-        }
-    occ[c] = (unsigned char)any;
+    if (c >= n_blocks) return;
+    unsigned any = 0;
+    for (int w = 0; w < words_per_block; w++) any |= mask[c * words_per_block + w];
+    occ[c] = any ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -543,7 +886,11 @@ struct rtx_ctx {
     DevBuf<float> ref_box, tight_box, bounds;
     DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp;
     DevBuf<unsigned char> cocc;
+    DevBuf<unsigned> wmask;
+    DevBuf<int> wpop, wpre, ostart;
+    DevBuf<uint2> words;
     DevGrid dgrid{};
+    DevSparse dsparse{};
     // frame workspace
     size_t ws_pixels = 0;
     int ws_levels = 0;
@@ -551,6 +898,7 @@ struct rtx_ctx {
     DevBuf<unsigned long long> work;
     DevBuf<float4> hP, hN, hD, rO[2], rD[2], hL[RTX_MAX_LEVELS];
     DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
+    DevBuf<float4> path_stack;
     DevBuf<float> rgb_local;
     DevBuf<int> ids_local;
     hipEvent_t ev[4 + 3 * 2 * RTX_MAX_LEVELS];
@@ -628,7 +976,7 @@ int ensure_workspace(rtx_ctx* c, size_t pixels, int levels) {
     levels = std::max(levels, c->ws_levels);
     int rc;
     if ((rc = c->counters.reserve(CNT_TOTAL))) return rc;
-    if ((rc = c->work.reserve(16))) return rc;
+    if ((rc = c->work.reserve(24))) return rc;
     if ((rc = c->hP.reserve(pixels)) || (rc = c->hN.reserve(pixels)) || (rc = c->hD.reserve(pixels))) return rc;
     if ((rc = c->pix0.reserve(pixels))) return rc;
     for (int k = 0; k < 2; k++)
@@ -648,6 +996,47 @@ void launch_level(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level, 
     if (timed) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL((k_shade<MODE, COUNT>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, f, level);
     if (timed) (void)hipEventRecord(ev[2], st);
+}
+
+template <int MODE, bool SINGLE_XF, bool COUNT>
+void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level, int blocks, hipStream_t st, bool timed,
+                    hipEvent_t* ev) {
+    if (timed) (void)hipEventRecord(ev[0], st);
+    hipLaunchKernelGGL((k_trace_w<MODE, SINGLE_XF, COUNT>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, level);
+    if (timed) (void)hipEventRecord(ev[1], st);
+    hipLaunchKernelGGL((k_shade_w<MODE, SINGLE_XF, COUNT>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, level);
+    if (timed) (void)hipEventRecord(ev[2], st);
+}
+
+template <int MODE>
+void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
+    const bool single = c->n_xforms == 1;
+    float4* ps = c->path_stack.p;
+    if (single) {
+        if (count) hipLaunchKernelGGL((k_frame<MODE, true, true>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        else hipLaunchKernelGGL((k_frame<MODE, true, false>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+    } else {
+        if (count) hipLaunchKernelGGL((k_frame<MODE, false, true>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        else hipLaunchKernelGGL((k_frame<MODE, false, false>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+    }
+}
+
+template <int MODE>
+void launch_level_any(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level, int blocks, hipStream_t st, bool timed,
+                      hipEvent_t* ev, bool count, bool serial) {
+    if (serial) {
+        if (count) launch_level<MODE, true>(c, sc, f, level, blocks, st, timed, ev);
+        else launch_level<MODE, false>(c, sc, f, level, blocks, st, timed, ev);
+        return;
+    }
+    const bool single = c->n_xforms == 1;
+    if (single) {
+        if (count) launch_level_w<MODE, true, true>(c, sc, f, level, blocks, st, timed, ev);
+        else launch_level_w<MODE, true, false>(c, sc, f, level, blocks, st, timed, ev);
+    } else {
+        if (count) launch_level_w<MODE, false, true>(c, sc, f, level, blocks, st, timed, ev);
+        else launch_level_w<MODE, false, false>(c, sc, f, level, blocks, st, timed, ev);
+    }
 }
 
 }  // namespace
@@ -693,9 +1082,11 @@ void rtx_destroy(rtx_ctx* c) {
     c->ref_box.release(); c->tight_box.release(); c->bounds.release();
     c->cstart.release(); c->cids.release(); c->fstart.release(); c->fids.release(); c->scratch_ids.release();
     c->cell_tmp.release(); c->cocc.release();
+    c->wmask.release(); c->wpop.release(); c->wpre.release(); c->ostart.release(); c->words.release();
     c->counters.release(); c->work.release(); c->hP.release(); c->hN.release(); c->hD.release(); c->pix0.release();
     for (int k = 0; k < 2; k++) { c->rO[k].release(); c->rD[k].release(); }
     for (int l = 0; l < RTX_MAX_LEVELS; l++) { c->hL[l].release(); c->hChild[l].release(); }
+    c->path_stack.release();
     c->rgb_local.release(); c->ids_local.release();
     delete c;
 }
@@ -788,7 +1179,8 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene_view* v) {
 // count -> scan -> scatter -> order, for one set of boxes and one resolution
 static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevBuf<int>& start, DevBuf<int>& ids, int64_t* n_refs) {
     const int n = c->n_prims;
-    const int64_t n_cells64 = (int64_t)bp.rx * bp.ry * bp.rz;
+    const int64_t n_cells64 = bp.sub > 0 ? (int64_t)(bp.rx / bp.sub) * (bp.ry / bp.sub) * (bp.rz / bp.sub) * bp.cpb
+                                         : (int64_t)bp.rx * bp.ry * bp.rz;
     if (n_cells64 > ((int64_t)1 << 27)) { rtx_set_error("grid of %lld cells exceeds the 2^27 cell limit", (long long)n_cells64); return RTX_E_LIMIT; }
     const int n_cells = (int)n_cells64;
     int rc;
@@ -850,6 +1242,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         bp.lo = g.lo; bp.size = g.size; bp.res = g.res;
         bp.rx = rx; bp.ry = ry; bp.rz = rz;
         bp.pad = 0.0f;
+        bp.sub = 0; bp.cpb = 0;
         if ((rc = build_lists(c, bp, c->ref_box.p, c->cstart, c->cids, &gi.n_refs))) return rc;
         g.cstart = c->cstart.p;
         g.cids = c->cids.p;
@@ -866,10 +1259,26 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         bp.lo = g.lo; bp.size = g.size; bp.res = mk((float)frx, (float)fry, (float)frz);
         bp.rx = frx; bp.ry = fry; bp.rz = frz;
         bp.pad = 2e-4f * std::max(g.size.x, std::max(g.size.y, g.size.z));
+        const int wpb = (sub * sub * sub + 31) / 32;
+        bp.sub = sub; bp.cpb = 32 * wpb;
         if ((rc = build_lists(c, bp, c->tight_box.p, c->fstart, c->fids, &gi.n_fine_refs))) return rc;
-        if ((rc = c->cocc.reserve((size_t)gi.n_cells))) return rc;
-        hipLaunchKernelGGL(k_occupancy, dim3(((int)gi.n_cells + 255) / 256), dim3(256), 0, 0, rx, ry, rz, sub, (const int*)c->fstart.p, c->cocc.p);
+        const int n_blocks = (int)gi.n_cells, n_words = n_blocks * wpb;
+        if ((rc = c->cocc.reserve((size_t)n_blocks)) || (rc = c->wmask.reserve((size_t)n_words)) || (rc = c->wpop.reserve((size_t)n_words)) ||
+            (rc = c->wpre.reserve((size_t)n_words + 1)) || (rc = c->words.reserve((size_t)n_words)))
+            return rc;
+        hipLaunchKernelGGL(k_words, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, c->wmask.p, c->wpop.p);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_words, (const int*)c->wpop.p, c->wpre.p);
+        int n_occ = 0;
+        HIP_TRY(hipMemcpy(&n_occ, c->wpre.p + n_words, sizeof(int), hipMemcpyDeviceToHost));
+        if ((rc = c->ostart.reserve((size_t)n_occ + 1))) return rc;
+        hipLaunchKernelGGL(k_compact, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, (const unsigned*)c->wmask.p,
+                           (const int*)c->wpre.p, c->words.p, c->ostart.p);
+        hipLaunchKernelGGL(k_occupancy, dim3((n_blocks + 255) / 256), dim3(256), 0, 0, n_blocks, wpb, (const unsigned*)c->wmask.p, c->cocc.p);
+        c->dsparse.words = c->words.p;
+        c->dsparse.ostart = c->ostart.p;
+        c->dsparse.words_per_block = wpb;
         g.sub = sub;
+        g.cpb = 32 * wpb;
         g.frx = frx; g.fry = fry; g.frz = frz;
         g.fcell = mk(g.size.x / (float)frx, g.size.y / (float)fry, g.size.z / (float)frz);
         g.inv_fcell = mk((float)frx / g.size.x, (float)fry / g.size.y, (float)frz / g.size.z);
@@ -877,7 +1286,8 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         g.fids = c->fids.p;
         g.cocc = c->cocc.p;
         gi.sub = sub;
-        gi.n_fine_cells = (int64_t)frx * fry * frz;
+        gi.n_fine_cells = (int64_t)n_blocks * 32 * wpb;
+        gi.n_occupied_fine_cells = n_occ;
         c->have_nested = true;
     }
     HIP_TRY(hipEventRecord(c->ev[1], 0));
@@ -946,7 +1356,16 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const int nl = count_local_rows(p->height, tile_rows, rank, world);
     const int levels = p->max_depth + 1;
     const size_t pixels = (size_t)nl * p->width;
-    if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
+    const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
+    const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
+    const int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the work cursors balance the rest
+    if (level_queues) {
+        if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
+    } else {
+        if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24)) ||
+            (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * levels)))
+            return rc;
+    }
     if (stats) memset(stats, 0, sizeof *stats);
     if (nl == 0) return RTX_OK;
 
@@ -959,39 +1378,42 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.n_items0 = f.nbx * ((nl + 7) / 8) * 64;
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
+    f.walk_budget = 2;
+    f.ready_threshold = 32;
+    if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
+    if (const char* e = getenv("RTX_READY_THRESHOLD")) f.ready_threshold = std::max(1, atoi(e));
     f.cam = make_camera(cam, p->width, p->height);
     f.rgb = d_rgb;
     f.ids = d_ids;
     f.counters = c->counters.p;
     f.work = c->work.p;
-    f.hP = c->hP.p; f.hN = c->hN.p; f.hD = c->hD.p; f.pix0 = c->pix0.p;
+    if (level_queues) { f.hP = c->hP.p; f.hN = c->hN.p; f.hD = c->hD.p; f.pix0 = c->pix0.p; }
 
     const DevScene sc = dev_scene(c);
     const bool count = (p->flags & RTX_RENDER_COUNT_WORK) != 0;
     const bool timed = stats != nullptr;
-    const int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the chunk cursor balances the rest
 
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
-    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 16 * sizeof(unsigned long long), st));
+    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 24 * sizeof(unsigned long long), st));
     hipEvent_t* ev = c->ev;
     HIP_TRY(hipEventRecord(ev[0], st));
-    for (int l = 0; l < levels; l++) {
+    if (!level_queues) {
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels);
+        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, blocks, st, count, levels);
+        HIP_TRY(hipEventRecord(ev[1], st));
+    }
+    for (int l = 0; level_queues && l < levels; l++) {
         hipEvent_t* le = ev + 4 + 3 * l;
         f.hL = c->hL[l].p;
         f.hChild = c->hChild[l].p;
         f.hChild_prev = l > 0 ? c->hChild[l - 1].p : nullptr;
         f.rO_in = c->rO[(l + 1) & 1].p; f.rD_in = c->rD[(l + 1) & 1].p;
         f.rO_out = c->rO[l & 1].p; f.rD_out = c->rD[l & 1].p;
-        if (p->search == RTX_SEARCH_REFERENCE_LISTS) {
-            if (count) launch_level<RT_SEARCH_REF, true>(c, sc, f, l, blocks, st, timed, le);
-            else launch_level<RT_SEARCH_REF, false>(c, sc, f, l, blocks, st, timed, le);
-        } else {
-            if (count) launch_level<RT_SEARCH_NESTED, true>(c, sc, f, l, blocks, st, timed, le);
-            else launch_level<RT_SEARCH_NESTED, false>(c, sc, f, l, blocks, st, timed, le);
-        }
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_level_any<RT_SEARCH_REF>(c, sc, f, l, blocks, st, timed, le, count, serial);
+        else launch_level_any<RT_SEARCH_NESTED>(c, sc, f, l, blocks, st, timed, le, count, serial);
     }
-    HIP_TRY(hipEventRecord(ev[1], st));
-    for (int l = levels - 1; l >= 0; l--) {
+    if (level_queues) HIP_TRY(hipEventRecord(ev[1], st));
+    for (int l = levels - 1; level_queues && l >= 0; l--) {
         f.hL = c->hL[l].p;
         f.hL_next = l + 1 < levels ? c->hL[l + 1].p : nullptr;
         f.hChild = c->hChild[l].p;
@@ -1011,17 +1433,27 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
             stats->shadow_rays += (int64_t)cnt[CNT_HITS + l] * c->n_lights;
             if (l < p->max_depth) stats->reflection_rays += cnt[CNT_HITS + l];
             float a = 0, b = 0;
-            (void)hipEventElapsedTime(&a, ev[4 + 3 * l], ev[4 + 3 * l + 1]);
-            (void)hipEventElapsedTime(&b, ev[4 + 3 * l + 1], ev[4 + 3 * l + 2]);
+            if (level_queues) {
+                (void)hipEventElapsedTime(&a, ev[4 + 3 * l], ev[4 + 3 * l + 1]);
+                (void)hipEventElapsedTime(&b, ev[4 + 3 * l + 1], ev[4 + 3 * l + 2]);
+            }
             stats->trace_ms += a;
             stats->shade_ms += b;
+            stats->level_trace_ms[l] = a;
+            stats->level_shade_ms[l] = b;
         }
-        stats->trace_launches = stats->shade_launches = stats->resolve_launches = levels;
         (void)hipEventElapsedTime(&stats->frame_ms, ev[0], ev[2]);
-        (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
+        if (level_queues) {
+            stats->trace_launches = stats->shade_launches = stats->resolve_launches = levels;
+            (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
+        } else {
+            stats->trace_launches = 1;                 // the persistent frame kernel does everything
+            (void)hipEventElapsedTime(&stats->trace_ms, ev[0], ev[1]);
+        }
         if (count) {
-            unsigned long long w[16];
+            unsigned long long w[24];
             HIP_TRY(hipMemcpy(w, c->work.p, sizeof w, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 4; k++) stats->wave_events[k] = (int64_t)w[16 + k];
             for (int k = 0; k < 8; k++) { stats->trace_work[k] = (int64_t)w[k]; stats->shade_work[k] = (int64_t)w[8 + k]; }
             stats->tri_tests = (int64_t)(w[0] + w[8]); stats->sphere_tests = (int64_t)(w[1] + w[9]);
             stats->xform_evals = (int64_t)(w[2] + w[10]); stats->cell_steps = (int64_t)(w[3] + w[11]);

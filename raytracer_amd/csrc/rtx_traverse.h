@@ -31,15 +31,19 @@ struct DevGrid {
     const int* cstart;          // reference cell lists, CSR over rx*ry*rz cells
     const int* cids;
     int sub;                    // fine cells per coarse cell and axis
+    int cpb;                    // fine cells per coarse cell in the block-major numbering (sub^3 padded to 32)
     int frx, fry, frz;          // fine resolution = r * sub
     f3 fcell, inv_fcell;        // fine cell edge and its reciprocal
-    const int* fstart;          // fine cell lists (tight padded boxes), CSR
+    const int* fstart;          // fine cell lists (tight padded boxes), CSR over cell = block * cpb + local,
+                                // block = coarse cell index, local = lx + sub * (ly + sub * lz)
     const int* fids;
     const unsigned char* cocc;  // per coarse cell: 1 if any nested fine cell holds a primitive
 };
 
 struct WorkCounters {
     unsigned long long tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits, rays;
+    // wave-level events (counted once per wave): rounds, walk-loop iterations, 64-pair test batches, state updates
+    unsigned long long w_rounds, w_walk_iters, w_test_batches, w_updates;
 };
 
 #define RT_KIND_TRI 0
@@ -233,7 +237,7 @@ __device__ bool traverse(const DevScene& sc, const DevGrid& g, f3 O, f3 D, float
             // every lane leaves this loop: each pass either breaks or moves one fine index toward the block edge
             for (;;) {
                 if (COUNT) wc.fine_steps++;
-                const int fc = fx + g.frx * (fy + g.fry * fz);
+                const int fc = cell * g.cpb + (fx - bx) + k * ((fy - by) + k * (fz - bz));
                 const int b = g.fstart[fc], e = g.fstart[fc + 1];
                 for (int j = b; j < e; j++) {
                     test_prim<COUNT>(sc, g.fids[j], O, D, t_exit, s, wc);
@@ -258,7 +262,8 @@ __device__ bool traverse(const DevScene& sc, const DevGrid& g, f3 O, f3 D, float
         if (t_exit == nx) { ix += sx; nx += dtx; }
         else if (t_exit == ny) { iy += sy; ny += dty; }
         else if (t_exit == nz) { iz += sz; nz += dtz; }
-        else if (t_exit == t_limit) return false;
+        else return false;   // t_exit == t_limit (:251-253); also taken when nothing compares equal (NaN), where the
+                             // reference would spin forever
         if (MODE == RT_SEARCH_NESTED) t_in = t_exit;
     }
     return false;

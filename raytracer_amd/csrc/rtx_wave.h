@@ -1,0 +1,339 @@
+// Wave-cooperative grid traversal for gfx950 (wave64).
+//
+// A wave owns 64 rays.  Each round has two phases:
+//   walk   every lane advances its own ray through the grid (the reference's coarse 3D-DDA,
+//          src/grid.h:149-257 of the reference tree, and for the nested search a fine 3D-DDA over an
+//          occupancy bitmask) until it stands on a cell that holds primitives;
+//   test   the (ray, primitive) candidate pairs of ALL lanes are spread over the 64 lanes: lane p takes
+//          pair p, finds its owner ray from the per-lane prefix sums staged in LDS, reads the owner's
+//          ray from LDS, gathers the primitive and runs the test; accepted hits are folded into the
+//          owner's best hit with a 64-bit LDS atomic min over (t bits, primitive index), which is the
+//          reference's "nearest, first in file order on ties" (src/geometries.h:184-187).
+// A ray's dependent-load chain is therefore one round per occupied cell it visits, not one per candidate,
+// and a lane whose ray has finished or has few candidates still runs tests for its neighbours.
+//
+// The arithmetic of the coarse walk and of the primitive tests is the per-lane code of rtx_traverse.h,
+// operation for operation; only who executes a test changes, so results are bit-identical to it.
+#pragma once
+#include "rtx_traverse.h"
+
+namespace rt {
+
+// Sparse view of the fine grid.  Fine cells are numbered block-major: cell = block * cells_per_block + local,
+// block = coarse cell index, local = lx + sub * (ly + sub * lz), cells_per_block = 32 * words_per_block
+// (padded).  Per 32 cells one uint2: x = occupancy mask, y = number of occupied cells before this word (over
+// the whole grid).  The lists of the occupied cells are CSR over that compact numbering (ostart), ids in fids.
+struct DevSparse {
+    const uint2* words;
+    const int* ostart;
+    int words_per_block;
+};
+
+struct __attribute__((aligned(16))) WaveLds {
+    float4 ray_a[64];              // ray origin xyz (in the space the tests run in), acceptance bound t < w
+    float4 ray_b[64];              // ray direction xyz, w = bits of (list start - exclusive prefix)
+    unsigned long long best[64];   // (t bits << 32) | primitive, all ones = none
+    int pre[64];                   // exclusive prefix sum of the lanes' candidate counts
+    int pre8[8];                   // pre[0], pre[8], ..., pre[56]
+};
+
+#define RT_BEST_NONE 0xffffffffffffffffull
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(v, off);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+// Per-lane walk state.  MODE = RT_SEARCH_REF: every coarse cell's reference list is a candidate list.
+// MODE = RT_SEARCH_NESTED: fine 3D-DDA inside occupied coarse cells, candidates = lists of occupied fine cells.
+// The advance steps are written with selects instead of branches: the three axes of a divergent wave would
+// otherwise run one after the other.
+template <int MODE>
+struct Walker {
+    f3 O, D;
+    float t_limit;
+    int ix, iy, iz;
+    float nx, ny, nz, dtx, dty, dtz;
+    float t_exit;
+    // nested
+    f3 inv_d;
+    float t_in;
+    int lx, ly, lz;      // fine cell inside the current coarse cell, each in [0, sub)
+    float fnx, fny, fnz; // ray parameter of the next fine crossing per axis
+    int word_base;       // index of the current coarse cell's first occupancy word
+    int cur_w;
+    uint2 cur;
+    int state;           // 0: about to enter coarse cell (ix,iy,iz); 1: inside its fine block; 2: finished
+    bool hit;
+
+    // collidesWithBox + start cell + first crossings (src/grid.h:91-138,156-227); same arithmetic as traverse()
+    __device__ __forceinline__ void init(const DevGrid& g, f3 o, f3 d, float tl, bool active) {
+        O = o; D = d; t_limit = tl;
+        hit = false;
+        state = 2;
+        cur_w = -1;
+        cur = make_uint2(0u, 0u);
+        ix = iy = iz = 0; nx = ny = nz = 0; dtx = dty = dtz = 0; t_exit = 0; t_in = 0;
+        lx = ly = lz = 0; fnx = fny = fnz = 0; word_base = 0;
+        inv_d = mk(0, 0, 0);
+        if (!active) return;
+        const float txs = (g.lo.x - O.x) / D.x, txe = (g.hi.x - O.x) / D.x;
+        const float tys = (g.lo.y - O.y) / D.y, tye = (g.hi.y - O.y) / D.y;
+        const float tzs = (g.lo.z - O.z) / D.z, tze = (g.hi.z - O.z) / D.z;
+        float tx0 = txs, tx1 = txe; if (D.x < 0) { tx0 = txe; tx1 = txs; }
+        float ty0 = tys, ty1 = tye; if (D.y < 0) { ty0 = tye; ty1 = tys; }
+        float tz0 = tzs, tz1 = tze; if (D.z < 0) { tz0 = tze; tz1 = tzs; }
+        const float t0 = max_of3(tx0, ty0, tz0), t1 = min_of3(tx1, ty1, tz1);
+        dtx = (tx1 - tx0) / g.res.x; dty = (ty1 - ty0) / g.res.y; dtz = (tz1 - tz0) / g.res.z;
+        if (!(t0 < t1 && t1 > 0.0001f)) return;
+        const bool inside = O.x > g.lo.x && O.x < g.hi.x && O.y > g.lo.y && O.y < g.hi.y && O.z > g.lo.z && O.z < g.hi.z;
+        const f3 pos = inside ? O : O + t0 * D;
+        ix = (int)clampf(floorf((pos.x - g.lo.x) * g.res.x / g.size.x), 0.0f, g.res.x - 1.0f);
+        iy = (int)clampf(floorf((pos.y - g.lo.y) * g.res.y / g.size.y), 0.0f, g.res.y - 1.0f);
+        iz = (int)clampf(floorf((pos.z - g.lo.z) * g.res.z / g.size.z), 0.0f, g.res.z - 1.0f);
+        nx = D.x > 0 ? tx0 + (float)(ix + 1) * dtx : (D.x < 0 ? tx0 + (float)(g.rx - ix) * dtx : FLT_MAX);
+        ny = D.y > 0 ? ty0 + (float)(iy + 1) * dty : (D.y < 0 ? ty0 + (float)(g.ry - iy) * dty : FLT_MAX);
+        nz = D.z > 0 ? tz0 + (float)(iz + 1) * dtz : (D.z < 0 ? tz0 + (float)(g.rz - iz) * dtz : FLT_MAX);
+        if (MODE == RT_SEARCH_NESTED) {
+            // the fine walk is acceleration only (its rounding is covered by the margin of the fine lists)
+            inv_d = mk(__frcp_rn(D.x), __frcp_rn(D.y), __frcp_rn(D.z));
+            t_in = inside ? 0.0f : t0;
+        }
+        state = 0;
+    }
+
+    // leave the current coarse cell without a hit: src/grid.h:239-253, then the loop condition :229
+    __device__ __forceinline__ void coarse_advance(const DevGrid& g) {
+        const bool ax = t_exit == nx;
+        const bool ay = !ax && t_exit == ny;
+        const bool az = !ax && !ay && t_exit == nz;
+        // no crossing equals the exit parameter: the ray ends at t_limit (src/grid.h:251-253).  The same exit is
+        // taken when nothing compares equal at all (a NaN parameter), where the reference would spin forever.
+        const bool stop = !ax && !ay && !az;
+        ix += ax ? (D.x > 0 ? 1 : -1) : 0;
+        iy += ay ? (D.y > 0 ? 1 : -1) : 0;
+        iz += az ? (D.z > 0 ? 1 : -1) : 0;
+        nx += ax ? dtx : 0.0f;   // adding +0 leaves every value, including infinities and NaN payloads, as it is
+        ny += ay ? dty : 0.0f;
+        nz += az ? dtz : 0.0f;
+        t_in = t_exit;
+        const bool in_grid = ix != (D.x > 0 ? g.rx : -1) && iy != (D.y > 0 ? g.ry : -1) && iz != (D.z > 0 ? g.rz : -1);
+        state = (stop || !in_grid) ? 2 : 0;
+    }
+
+    // Leave the current fine cell.  With an accepted hit in hand (found) the ray finishes as soon as the hit
+    // lies before the next fine cell, or when the walk leaves the block; without one the walk goes on, into
+    // the next coarse cell when it leaves the block.
+    __device__ __forceinline__ void fine_advance(const DevGrid& g, bool found, float best_t) {
+        const int k = g.sub;
+        const float tc = fminf(fnx, fminf(fny, fnz));
+        const bool done = found && best_t < tc;
+        const bool beyond = !(tc < t_exit);               // the remaining fine cells begin beyond the coarse exit
+        const bool ax = tc == fnx;
+        const bool ay = !ax && tc == fny;
+        const bool az = !ax && !ay;
+        lx += ax ? (D.x > 0 ? 1 : -1) : 0;
+        ly += ay ? (D.y > 0 ? 1 : -1) : 0;
+        lz += az ? (D.z > 0 ? 1 : -1) : 0;
+        fnx += ax ? fabsf(g.fcell.x * inv_d.x) : 0.0f;
+        fny += ay ? fabsf(g.fcell.y * inv_d.y) : 0.0f;
+        fnz += az ? fabsf(g.fcell.z * inv_d.z) : 0.0f;
+        const bool outside = (unsigned)lx >= (unsigned)k || (unsigned)ly >= (unsigned)k || (unsigned)lz >= (unsigned)k;
+        if (done) { state = 2; hit = true; }
+        else if (beyond || outside) {
+            if (found) { state = 2; hit = true; }
+            else coarse_advance(g);
+        }
+    }
+
+    // Walks until the lane stands on a candidate list (returns true and fills start/count), finishes, or has
+    // used `budget` steps.  Every step either finishes the ray or moves a cell index monotonically toward the
+    // grid boundary, so the walk terminates.
+    template <bool COUNT>
+    __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, int budget, int& start, int& count,
+                                         bool found, float best_t, WorkCounters& wc) {
+        while (state != 2 && budget-- > 0) {
+            if (COUNT) wc.w_walk_iters++;
+            if (state == 0) {
+                if (COUNT) wc.cell_steps++;
+                t_exit = min_of4(nx, ny, nz, t_limit);
+                const int cell = ix + g.rx * iy + g.rx * g.ry * iz;
+                if (MODE == RT_SEARCH_REF) {
+                    const int b = g.cstart[cell], e = g.cstart[cell + 1];
+                    if (e > b) { start = b; count = e - b; return true; }
+                    coarse_advance(g);
+                } else if (g.cocc[cell]) {
+                    const int k = g.sub;
+                    const f3 p = O + fmaxf(t_in, 0.0f) * D;
+                    const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - ix * k, 0), k - 1);
+                    const int fy = min(max((int)floorf((p.y - g.lo.y) * g.inv_fcell.y) - iy * k, 0), k - 1);
+                    const int fz = min(max((int)floorf((p.z - g.lo.z) * g.inv_fcell.z) - iz * k, 0), k - 1);
+                    lx = fx; ly = fy; lz = fz;
+                    const float inf = __builtin_inff();
+                    const float px = g.lo.x + (float)(ix * k + fx + (D.x > 0 ? 1 : 0)) * g.fcell.x;
+                    const float py = g.lo.y + (float)(iy * k + fy + (D.y > 0 ? 1 : 0)) * g.fcell.y;
+                    const float pz = g.lo.z + (float)(iz * k + fz + (D.z > 0 ? 1 : 0)) * g.fcell.z;
+                    fnx = D.x != 0 ? (px - O.x) * inv_d.x : inf;
+                    fny = D.y != 0 ? (py - O.y) * inv_d.y : inf;
+                    fnz = D.z != 0 ? (pz - O.z) * inv_d.z : inf;
+                    word_base = cell * sp.words_per_block;
+                    state = 1;
+                } else {
+                    coarse_advance(g);
+                }
+            }
+            if (MODE == RT_SEARCH_NESTED && state == 1) {
+                if (COUNT) wc.fine_steps++;
+                const int k = g.sub;
+                const int local = lx + k * (ly + k * lz);
+                const int w = word_base + (local >> 5);
+                if (w != cur_w) { cur = sp.words[w]; cur_w = w; }
+                const unsigned bit = 1u << (local & 31);
+                if (cur.x & bit) {
+                    const int o = (int)cur.y + __popc(cur.x & (bit - 1u));
+                    const int b = sp.ostart[o], e = sp.ostart[o + 1];
+                    start = b; count = e - b;
+                    return true;
+                }
+                fine_advance(g, found, best_t);
+            }
+        }
+        return false;
+    }
+
+    // after the candidates of the current cell were tested
+    __device__ __forceinline__ void after_tests(const DevGrid& g, bool found, float best_t, bool any_hit) {
+        if (MODE == RT_SEARCH_REF) {
+            if (found) { state = 2; hit = true; }
+            else coarse_advance(g);
+        } else {
+            if (found && any_hit) { state = 2; hit = true; }
+            else fine_advance(g, found, best_t);
+        }
+    }
+};
+
+// One test of pair (owner ray, primitive).  SINGLE_XF: the scene has exactly one transform and the LDS holds the
+// ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed by its
+// primitive's inverse here (src/geometries.h:179-180).
+template <bool SINGLE_XF, bool COUNT>
+__device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, int pid,
+                                          WorkCounters& wc) {
+    const float4 q0 = sc.prims[3 * pid], q1 = sc.prims[3 * pid + 1], q2 = sc.prims[3 * pid + 2];
+    if (!SINGLE_XF) {
+        const float* m = sc.xinv + 16 * as_int(q2.y);
+        const f3 Ow = Oo, Dw = Do;
+        Oo = mul_point(m, Ow);
+        Do = mul_dir(m, Dw);
+        if (COUNT) wc.xform_evals++;
+    }
+    float t;
+    bool ok;
+    if (as_int(q2.w) == RT_KIND_TRI) {
+        if (COUNT) wc.tri_tests++;
+        ok = hit_triangle(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), Oo, Do, t);
+    } else {
+        if (COUNT) wc.sphere_tests++;
+        ok = hit_sphere(mk(q0.x, q0.y, q0.z), q0.w, Oo, Do, t);
+    }
+    if (ok && t < bound) {
+        // t > 0 here, so its bit pattern orders like its value; the low word breaks ties toward the lower index
+        const unsigned long long key = ((unsigned long long)(unsigned)as_int(t) << 32) | (unsigned)pid;
+        atomicMin(&l.best[owner], key);
+    }
+}
+
+// Per-lane search state that lives beside the Walker: the ray in the space the tests run in and the best hit.
+struct LaneSearch {
+    f3 Or, Dr;
+    bool found;
+    float best_t;
+    int best_prim;
+};
+
+// Starts a new ray on the calling lanes (others keep theirs).  May be called under divergence.
+template <int MODE, bool SINGLE_XF, bool COUNT>
+__device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, WaveLds& l, Walker<MODE>& w, LaneSearch& r, f3 O, f3 D,
+                                          float t_limit, WorkCounters& wc) {
+    w.init(g, O, D, t_limit, true);
+    if (COUNT) wc.rays++;
+    r.Or = O;
+    r.Dr = D;
+    if (SINGLE_XF) {
+        r.Or = mul_point(sc.xinv, O);
+        r.Dr = mul_dir(sc.xinv, D);
+        if (COUNT) wc.xform_evals++;
+    }
+    r.found = false;
+    r.best_t = FLT_MAX;
+    r.best_prim = -1;
+    l.best[lane_id()] = RT_BEST_NONE;
+}
+
+// One round for the whole wave: every lane with an unfinished ray walks to its next candidate list, the
+// candidate pairs of all lanes are tested by all lanes, and each lane folds its result into its walk.
+// any_hit is per lane.  Must be called by all 64 lanes in convergent control flow.
+template <int MODE, bool SINGLE_XF, bool COUNT>
+__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, WaveLds& l, Walker<MODE>& w,
+                                           LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
+    const int lane = lane_id();
+    int start = 0, count = 0;
+    if (COUNT) wc.w_rounds++;
+    const bool pending = w.template walk<COUNT>(g, sp, budget, start, count, r.found, r.best_t, wc);
+    if (!pending) count = 0;
+    const int incl = wave_inclusive_scan(count);
+    const int total = __shfl(incl, 63);
+    if (total > 0) {
+        const int excl = incl - count;
+        l.ray_a[lane] = make_float4(r.Or.x, r.Or.y, r.Or.z, w.t_exit);
+        l.ray_b[lane] = make_float4(r.Dr.x, r.Dr.y, r.Dr.z, as_float(start - excl));
+        l.pre[lane] = excl;
+        if ((lane & 7) == 0) l.pre8[lane >> 3] = excl;
+        const int* ids = MODE == RT_SEARCH_REF ? g.cids : g.fids;
+        for (int base = 0; base < total; base += 64) {
+            if (COUNT) wc.w_test_batches++;
+            const int p = base + lane;
+            if (p < total) {
+                // owner = last lane whose exclusive prefix is <= p: two 8-way steps over the sorted prefixes
+                const int4 ga = *(const int4*)&l.pre8[0], gb = *(const int4*)&l.pre8[4];
+                const int grp = (ga.y <= p) + (ga.z <= p) + (ga.w <= p) + (gb.x <= p) + (gb.y <= p) + (gb.z <= p) + (gb.w <= p);
+                const int4 ha = *(const int4*)&l.pre[8 * grp], hb = *(const int4*)&l.pre[8 * grp + 4];
+                const int owner = 8 * grp + (ha.y <= p) + (ha.z <= p) + (ha.w <= p) + (hb.x <= p) + (hb.y <= p) + (hb.z <= p) + (hb.w <= p);
+                const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
+                const int pid = ids[as_int(rb.w) + p];
+                test_pair<SINGLE_XF, COUNT>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, pid, wc);
+            }
+        }
+    }
+    if (pending) {
+        const unsigned long long b = l.best[lane];
+        r.found = b != RT_BEST_NONE;
+        if (r.found) { r.best_t = as_float((int)(b >> 32)); r.best_prim = (int)(b & 0xffffffffull); }
+        w.after_tests(g, r.found, r.best_t, any_hit);
+    }
+}
+
+// Traces the wave's 64 rays to completion (a lane without a ray passes active = false).  Returns per lane
+// whether its ray hit; t_hit / prim_hit are the accepted hit.  Must be called by all 64 lanes together.
+template <int MODE, bool ANY, bool SINGLE_XF, bool COUNT>
+__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, WaveLds& l, f3 O, f3 D, float t_limit,
+                           bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
+    Walker<MODE> w;
+    LaneSearch r;
+    w.init(g, O, D, t_limit, false);
+    r.Or = O; r.Dr = D; r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
+    if (active) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, t_limit, wc);
+    while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
+    t_hit = r.best_t;
+    prim_hit = r.best_prim;
+    return w.hit;
+}
+
+}  // namespace rt

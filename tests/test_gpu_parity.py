@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 
 FLOAT_TOL = 1e-6          # absolute, on colours in [0, 1]
 MODES = [rt.SEARCH_REFERENCE_LISTS, rt.SEARCH_NESTED]
+# kernel pipelines: persistent per-wave path pools (default), level-synchronous global queues with the wave-cooperative
+# traversal, and the same with one lane per ray
+PIPELINES = {"frame": {}, "levels": {"level_queues": True}, "serial": {"serial_lanes": True}}
 GOLDEN_SCENES = ["scene1", "scene4-specular", "scene5", "scene6", "scene7"]
 
 
@@ -43,15 +46,17 @@ def test_grid_build_matches_reference_lists(renderer, name):
     assert np.array_equal(start, rstart) and np.array_equal(ids, rids)      # same cells, same order
     fstart, fids = renderer.download_grid(rt.GRID_NESTED)
     assert fstart[0] == 0 and fstart[-1] == len(fids) == gi.n_fine_refs and np.all(np.diff(fstart) >= 0)
-    assert gi.n_fine_cells == 15 ** 3 * gi.sub ** 3
+    assert gi.n_fine_cells == 15 ** 3 * 32 * ((gi.sub ** 3 + 31) // 32)          # blocks are padded to whole mask words
+    assert gi.n_occupied_fine_cells == int((np.diff(fstart) > 0).sum())
 
 
+@pytest.mark.parametrize("pipeline", list(PIPELINES))
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
-def test_render_matches_golden(renderer, name, mode):
+def test_render_matches_golden(renderer, name, mode, pipeline):
     g = np.load(os.path.join(GOLDEN, f"golden_{name}.npz"))
     load(renderer, name)
-    rgb, ids, st = renderer.render(int(g["width"]), int(g["height"]), 5, mode, count_work=True)
+    rgb, ids, st = renderer.render(int(g["width"]), int(g["height"]), 5, mode, count_work=True, **PIPELINES[pipeline])
     assert_image_parity(rgb, ids, g["rgb"], g["ids"])
     cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
     assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
@@ -59,7 +64,13 @@ def test_render_matches_golden(renderer, name, mode):
     if mode == rt.SEARCH_REFERENCE_LISTS:
         # the same candidates as the reference, minus the ones skipped after a shadow ray's first accepted hit
         assert st.tri_tests <= cnt["tri_tests"] and st.sphere_tests <= cnt["sph_tests"]
-        assert st.trace_work[0] + st.trace_work[1] > 0 or cnt["tri_tests"] + cnt["sph_tests"] == 0
+        assert st.tri_tests + st.sphere_tests > 0 or cnt["tri_tests"] + cnt["sph_tests"] == 0
+    if pipeline == "serial" and mode == rt.SEARCH_REFERENCE_LISTS:
+        pass
+    elif mode == rt.SEARCH_REFERENCE_LISTS:
+        # the wave-cooperative kernels test every candidate of a cell before looking at the result: exactly the
+        # reference's candidate set
+        assert st.tri_tests == cnt["tri_tests"] and st.sphere_tests == cnt["sph_tests"]
 
 
 @pytest.mark.parametrize("name,w,h", [("scene1", 640, 480), ("scene4-specular", 640, 480), ("scene6", 640, 480),
@@ -82,6 +93,10 @@ def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
     rgb_r, ids_r, st_r = renderer.render(W, H, 5, rt.SEARCH_REFERENCE_LISTS)
     assert np.array_equal(ids_n, ids_r)
     assert np.array_equal(rgb_n.view(np.int32), rgb_r.view(np.int32))
+    for kw in (PIPELINES["levels"], PIPELINES["serial"]):        # every pipeline computes the same frame
+        rgb_l, ids_l, st_l = renderer.render(W, H, 5, rt.SEARCH_NESTED, **kw)
+        assert np.array_equal(ids_l, ids_n) and np.array_equal(rgb_l.view(np.int32), rgb_n.view(np.int32))
+        assert list(st_l.hits_per_level) == list(st_n.hits_per_level)
     hits = list(st_n.hits_per_level)[:6]
     assert hits == list(st_r.hits_per_level)[:6] and hits[0] == int((ids_n >= 0).sum())
     assert st_n.shadow_rays == sum(hits) and st_n.reflection_rays == sum(hits[:5]) and st_n.primary_rays == W * H

@@ -29,9 +29,11 @@ for name, w, h in cases:
                np.array_equal(rstart, gstart) and np.array_equal(rids, gids))
     print(f"{name}: prims {sr.n_prims} grid refs {gi.n_refs} fine(sub={gi.sub}) refs {gi.n_fine_refs} "
           f"build {gi.build_ms:.2f} ms grid_identical={grid_ok}  oracle {sec:.2f}s", flush=True)
-    for mode, mname in [(rt.SEARCH_REFERENCE_LISTS, "ref-lists"), (rt.SEARCH_NESTED, "nested")]:
-        rgb, ids, st = r.render(w, h, 5, mode, count_work=True)
-        rgb2, ids2, st2 = r.render(w, h, 5, mode)
+    for mode, mname, serial, lq in [(rt.SEARCH_REFERENCE_LISTS, "ref-frame", False, False), (rt.SEARCH_NESTED, "nest-frame", False, False),
+                                    (rt.SEARCH_REFERENCE_LISTS, "ref-levels", False, True), (rt.SEARCH_NESTED, "nest-levels", False, True),
+                                    (rt.SEARCH_NESTED, "nest-serial", True, True)]:
+        rgb, ids, st = r.render(w, h, 5, mode, count_work=True, serial_lanes=serial, level_queues=lq)
+        rgb2, ids2, st2 = r.render(w, h, 5, mode, serial_lanes=serial, level_queues=lq)
         same_ids = np.array_equal(ids, ids_ref)
         n_id_diff = int((ids != ids_ref).sum())
         bit_same = np.array_equal(rgb.view(np.int32), rgb_ref.view(np.int32))

@@ -1,7 +1,10 @@
-"""Development timing run on the GPU box: scene7 @ 4K for several nested sub-resolutions and the reference lists."""
+"""Development timing run on the GPU box: one scene at one size for several nested sub-resolutions, both kernel
+families (wave-cooperative / one lane per ray), optionally the reference lists.
+
+    python tools/gpu_perf.py scene7 3840 2160 8,12 [noref] [noserial]
+"""
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,41 +15,50 @@ import raytracer_amd as rt
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 scene = sys.argv[1] if len(sys.argv) > 1 else "scene7"
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 2160)
-subs = [int(s) for s in sys.argv[4].split(",")] if len(sys.argv) > 4 else [4, 6, 8, 12, 16]
-do_ref = (sys.argv[5] != "noref") if len(sys.argv) > 5 else True
+subs = [int(s) for s in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8, 12]
+do_ref = "noref" not in sys.argv
+do_serial = "noserial" not in sys.argv
 sr = rt.SceneReader().readScene(os.path.join(ROOT, "scenes", scene + ".test"))
 r = rt.Renderer(0)
 r.set_scene(sr)
 d_rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 d_ids = torch.empty((H, W), dtype=torch.int32, device="cuda")
-base_ids = None
-base_rgb = None
-for sub in subs:
-    gi = r.build_grid(15, sub)
-    st = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, want_stats=True, count_work=True)
+base = None
+
+
+def run(search, serial, label, lq=True):
+    global base
+    st = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=search, want_stats=True, count_work=True,
+                         serial_lanes=serial, level_queues=lq)
     torch.cuda.synchronize()
     times = []
-    for it in range(5):
-        st2 = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, want_stats=True)
-        times.append((st2.frame_ms, st2.trace_ms, st2.shade_ms, st2.resolve_ms))
+    for _ in range(5):
+        s2 = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=search, want_stats=True, serial_lanes=serial, level_queues=lq)
+        times.append((s2.frame_ms, s2.trace_ms, s2.shade_ms, s2.resolve_ms))
     t = np.median(np.array(times), axis=0)
-    ids = d_ids.cpu().numpy()
-    rgb = d_rgb.cpu().numpy()
-    if base_ids is None:
-        base_ids, base_rgb = ids, rgb
-    print(f"sub={sub:2d} fine refs {gi.n_fine_refs} build {gi.build_ms:.1f} ms | frame {t[0]:.3f} ms trace {t[1]:.3f} shade {t[2]:.3f} "
-          f"resolve {t[3]:.3f} | rays {st.total_rays} ({st.primary_rays}/{st.shadow_rays}/{st.reflection_rays}) "
-          f"Mrays/s {st.total_rays / t[0] / 1e3:.1f} | tri {st.tri_tests} sph {st.sphere_tests} cells {st.cell_steps} fine {st.fine_steps} "
-          f"| same ids {np.array_equal(ids, base_ids)} same rgb {np.array_equal(rgb.view(np.int32), base_rgb.view(np.int32))}", flush=True)
+    ids, rgb = d_ids.cpu().numpy(), d_rgb.cpu().numpy()
+    if base is None:
+        base = (ids, rgb)
+    same_ids = np.array_equal(ids, base[0])
+    same_rgb = np.array_equal(rgb.view(np.int32), base[1].view(np.int32))
+    print(f"{label}: frame {t[0]:.3f} ms trace {t[1]:.3f} shade {t[2]:.3f} resolve {t[3]:.3f} | rays {st.total_rays} "
+          f"Mrays/s {st.total_rays / t[0] / 1e3:.1f} | tri {st.tri_tests} sph {st.sphere_tests} cells {st.cell_steps} "
+          f"fine {st.fine_steps} | wave events (rounds, walk iters, test batches, updates) {list(st.wave_events)} | same ids {same_ids} same rgb {same_rgb}", flush=True)
+    print("     per level trace ms", [round(v, 3) for v in list(s2.level_trace_ms)[:6]], "shade ms",
+          [round(v, 3) for v in list(s2.level_shade_ms)[:6]], "hits", list(s2.hits_per_level)[:6], flush=True)
+
+
+for sub in subs:
+    gi = r.build_grid(15, sub)
+    print(f"sub={gi.sub}: fine cells {gi.n_fine_cells} occupied {gi.n_occupied_fine_cells} refs {gi.n_fine_refs} "
+          f"build {gi.build_ms:.1f} ms", flush=True)
+    run(rt.SEARCH_NESTED, False, f"  nested sub={gi.sub} frame ", lq=False)
+    run(rt.SEARCH_NESTED, False, f"  nested sub={gi.sub} levels")
+    if do_serial:
+        run(rt.SEARCH_NESTED, True, f"  nested sub={gi.sub} serial")
 if do_ref:
-    t0 = time.time()
-    st = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=rt.SEARCH_REFERENCE_LISTS, want_stats=True, count_work=True)
-    ids = d_ids.cpu().numpy()
-    rgb = d_rgb.cpu().numpy()
-    st2 = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=rt.SEARCH_REFERENCE_LISTS, want_stats=True)
-    print(f"ref-lists frame {st2.frame_ms:.3f} ms trace {st2.trace_ms:.3f} shade {st2.shade_ms:.3f} | Mrays/s {st.total_rays / st2.frame_ms / 1e3:.1f} "
-          f"| tri {st.tri_tests} sph {st.sphere_tests} cells {st.cell_steps} | same ids as nested {np.array_equal(ids, base_ids)} "
-          f"({int((ids != base_ids).sum())} differ) same rgb {np.array_equal(rgb.view(np.int32), base_rgb.view(np.int32))} "
-          f"({int((rgb.view(np.int32) != base_rgb.view(np.int32)).any(axis=2).sum())} pixels differ)", flush=True)
-    print("hits per level", list(st.hits_per_level)[:6])
+    run(rt.SEARCH_REFERENCE_LISTS, False, "  reference lists frame ", lq=False)
+    run(rt.SEARCH_REFERENCE_LISTS, False, "  reference lists levels")
+    if do_serial:
+        run(rt.SEARCH_REFERENCE_LISTS, True, "  reference lists serial")
 r.close()
