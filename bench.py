@@ -162,6 +162,15 @@ def main():
             "hbm_algorithmic_GBs": frame_bytes / (kern[0] * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
             "traffic": None,
         }
+        # memory-side bytes per launch from the last committed rocprofv3 PMC passes of this same kernel and frame
+        # (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as gfx950 requires); bench.py itself does
+        # not run the profiler
+        import glob
+        traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if traffic_files and world == 1 and args.search == "nested":
+            with open(traffic_files[-1]) as fh:
+                roofline["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
         out = {
             "metric": "Mrays/sec (primary+shadow+reflection) on scene7 @4K", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
