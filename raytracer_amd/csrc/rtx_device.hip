@@ -348,6 +348,8 @@ template <int MODE, bool SINGLE_XF, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, int level) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     WaveLds& l = lds[threadIdx.x >> 6];
+    __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
+    const unsigned* occ = stage_occupancy(g, occ_lds);
     WorkCounters wc = {};
     const int lane = wave_lane();
     const int n = (level == 0) ? f.n_items0 : f.counters[CNT_HITS + level - 1];
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, D
         const f3 Dn = normalize3(D);
         float t = 0;
         int prim = -1;
-        const bool hit = trace_wave<MODE, false, SINGLE_XF, COUNT>(sc, g, sp, l, O, Dn, FLT_MAX, active, t, prim, wc);
+        const bool hit = trace_wave<MODE, false, SINGLE_XF, COUNT>(sc, g, sp, occ, l, O, Dn, FLT_MAX, active, t, prim, wc);
         const int slot = wave_alloc(f.counters + CNT_HITS + level, hit);
         if (hit) {
             if (COUNT) wc.nearest_hits++;
@@ -416,6 +418,8 @@ template <int MODE, bool SINGLE_XF, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, int level) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     WaveLds& l = lds[threadIdx.x >> 6];
+    __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
+    const unsigned* occ = stage_occupancy(g, occ_lds);
     WorkCounters wc = {};
     const int lane = wave_lane();
     const int n = f.counters[CNT_HITS + level];
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
             const float tL = point ? dot3(lpos - P, L) : FLT_MAX;
             float t;
             int prim;
-            const bool occluded = trace_wave<MODE, true, SINGLE_XF, COUNT>(sc, g, sp, l, So, L, tL, active, t, prim, wc);
+            const bool occluded = trace_wave<MODE, true, SINGLE_XF, COUNT>(sc, g, sp, occ, l, So, L, tL, active, t, prim, wc);
             if (active && !occluded) {
                 if (COUNT) wc.light_evals++;
                 const f3 c = light_term(rayDir, L, N, kd, ks, shininess, lcol);
@@ -474,24 +478,30 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
 // Results are bit-identical to the level-synchronous kernels: every ray and every term is computed by the
 // same code, only the schedule differs.
 // ---------------------------------------------------------------------------------------------------
+#define RTX_LDS_LEVELS 6              // paths up to this many levels keep their per-level terms in LDS
+
 template <int MODE, bool SINGLE_XF, bool COUNT>
 __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
+    __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+    __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
+    const unsigned* occ = stage_occupancy(g, occ_lds);
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
-    float4* stack = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
+    // per-level terms of this lane's path: LDS when the depth allows, else a private strip of global memory
+    const bool stack_in_lds = levels <= RTX_LDS_LEVELS;
+    float4* stack_g = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
     WorkCounters wc = {};
 
-    // path state of this lane
+    // path state of this lane; the ray in flight lives in the walker (w.O, w.D, w.t_limit)
     int pix = -1, level = 0, phase = 0, material = 0;   // phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i
-    f3 O = mk(0, 0, 0), D = mk(0, 0, 1), rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
-    float tl = FLT_MAX;
+    f3 rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
     Walker<MODE> w;
     LaneSearch r;
-    w.init(g, O, D, tl, false);
-    r.Or = O; r.Dr = D; r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
+    w.init(g, mk(0, 0, 0), mk(0, 0, 1), FLT_MAX, false);
+    r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
     bool exhausted = false;
 
     for (;;) {
@@ -501,6 +511,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
         if (!__any(walking) || n_ready >= f.ready_threshold) {
             if (COUNT) wc.w_updates++;
             bool begin = false;
+            f3 O = w.O, D = w.D;
+            float tl = w.t_limit;
             if (finished) {
                 bool path_end = false, lit = false;
                 int top = -1, next_light = -1;
@@ -537,7 +549,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 if (lit) {                                      // src/main.cpp:85-102
                     const float* m = sc.mats + 16 * material;
                     const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
-                    stack[level] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                    const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                    if (stack_in_lds) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
                     if (level < f.max_depth) {
                         const f3 V = normalize3(-rayDir);
                         const f3 R = (2.0f * dot3(V, N) * N) - V;
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 if (path_end) {
                     f3 C = mk(0, 0, 0);
                     for (int d = top; d >= 0; d--) {
-                        const float4 s4 = stack[d];
+                        const float4 s4 = stack_in_lds ? stack_lds[wave][d][lane] : stack_g[d];
                         const float* m = sc.mats + 16 * as_int(s4.w);
                         C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
                     }
@@ -610,7 +623,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
             if (exhausted && !__any(pix >= 0)) break;
         }
-        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, l, w, r, phase != 0, f.walk_budget, wc);
+        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, l, w, r, phase != 0, f.walk_budget, wc);
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
     if (COUNT) flush_work(wc, f.work);
@@ -843,6 +856,14 @@ __global__ void k_occupancy(int n_blocks, int words_per_block, const unsigned* m
     for (int w = 0; w < words_per_block; w++) any |= mask[c * words_per_block + w];
     occ[c] = any ? 1 : 0;
 }
+// ... and the same packed 32 coarse cells per word
+__global__ void k_occupancy_bits(int n_blocks, const unsigned char* occ, unsigned* bits) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= (n_blocks + 31) / 32) return;
+    unsigned m = 0;
+    for (int b = 0; b < 32 && 32 * w + b < n_blocks; b++) m |= occ[32 * w + b] ? (1u << b) : 0u;
+    bits[w] = m;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -886,7 +907,7 @@ struct rtx_ctx {
     DevBuf<float> ref_box, tight_box, bounds;
     DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp;
     DevBuf<unsigned char> cocc;
-    DevBuf<unsigned> wmask;
+    DevBuf<unsigned> wmask, cocc_bits;
     DevBuf<int> wpop, wpre, ostart;
     DevBuf<uint2> words;
     DevGrid dgrid{};
@@ -1082,7 +1103,7 @@ void rtx_destroy(rtx_ctx* c) {
     c->ref_box.release(); c->tight_box.release(); c->bounds.release();
     c->cstart.release(); c->cids.release(); c->fstart.release(); c->fids.release(); c->scratch_ids.release();
     c->cell_tmp.release(); c->cocc.release();
-    c->wmask.release(); c->wpop.release(); c->wpre.release(); c->ostart.release(); c->words.release();
+    c->wmask.release(); c->cocc_bits.release(); c->wpop.release(); c->wpre.release(); c->ostart.release(); c->words.release();
     c->counters.release(); c->work.release(); c->hP.release(); c->hN.release(); c->hD.release(); c->pix0.release();
     for (int k = 0; k < 2; k++) { c->rO[k].release(); c->rD[k].release(); }
     for (int l = 0; l < RTX_MAX_LEVELS; l++) { c->hL[l].release(); c->hChild[l].release(); }
@@ -1274,6 +1295,9 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         hipLaunchKernelGGL(k_compact, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, (const unsigned*)c->wmask.p,
                            (const int*)c->wpre.p, c->words.p, c->ostart.p);
         hipLaunchKernelGGL(k_occupancy, dim3((n_blocks + 255) / 256), dim3(256), 0, 0, n_blocks, wpb, (const unsigned*)c->wmask.p, c->cocc.p);
+        if ((rc = c->cocc_bits.reserve((size_t)(n_blocks + 31) / 32))) return rc;
+        hipLaunchKernelGGL(k_occupancy_bits, dim3(((n_blocks + 31) / 32 + 255) / 256), dim3(256), 0, 0, n_blocks, (const unsigned char*)c->cocc.p, c->cocc_bits.p);
+        g.cocc_bits = c->cocc_bits.p;
         c->dsparse.words = c->words.p;
         c->dsparse.ostart = c->ostart.p;
         c->dsparse.words_per_block = wpb;

@@ -38,6 +38,7 @@ struct DevGrid {
                                 // block = coarse cell index, local = lx + sub * (ly + sub * lz)
     const int* fids;
     const unsigned char* cocc;  // per coarse cell: 1 if any nested fine cell holds a primitive
+    const unsigned* cocc_bits;  // the same as a bit mask, 32 coarse cells per word
 };
 
 struct WorkCounters {

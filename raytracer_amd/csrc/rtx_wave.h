@@ -41,13 +41,17 @@ struct __attribute__((aligned(16))) WaveLds {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS round trips): four shifted
+// adds inside each row of 16 lanes, then the totals of rows 0 and 2 are broadcast into rows 1 and 3 (row_bcast:15,
+// row mask 0b1010) and the total of rows 0-1 into rows 2-3 (row_bcast:31, row mask 0b1100).  Lanes without a
+// source lane add the `old` operand, 0.  Every lane must be active.
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(v, off);
-        if (lane >= off) v += u;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
     return v;
 }
 
@@ -157,8 +161,8 @@ struct Walker {
     // used `budget` steps.  Every step either finishes the ray or moves a cell index monotonically toward the
     // grid boundary, so the walk terminates.
     template <bool COUNT>
-    __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, int budget, int& start, int& count,
-                                         bool found, float best_t, WorkCounters& wc) {
+    __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, const unsigned* occ, int budget, int& start,
+                                         int& count, bool found, float best_t, WorkCounters& wc) {
         while (state != 2 && budget-- > 0) {
             if (COUNT) wc.w_walk_iters++;
             if (state == 0) {
@@ -169,7 +173,7 @@ struct Walker {
                     const int b = g.cstart[cell], e = g.cstart[cell + 1];
                     if (e > b) { start = b; count = e - b; return true; }
                     coarse_advance(g);
-                } else if (g.cocc[cell]) {
+                } else if ((occ[cell >> 5] >> (cell & 31)) & 1u) {
                     const int k = g.sub;
                     const f3 p = O + fmaxf(t_in, 0.0f) * D;
                     const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - ix * k, 0), k - 1);
@@ -250,9 +254,19 @@ __device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int ow
     }
 }
 
+// Coarse-cell occupancy bits of the nested grid: staged in LDS by the whole workgroup when the grid is small enough
+// (the reference's 15^3 grid is 106 words), else read from global memory.  Returns the pointer the walkers use.
+#define RT_OCC_LDS_WORDS 128
+__device__ __forceinline__ const unsigned* stage_occupancy(const DevGrid& g, unsigned* lds_words) {
+    const int n_words = (g.rx * g.ry * g.rz + 31) >> 5;
+    if (g.cocc_bits == nullptr || n_words > RT_OCC_LDS_WORDS) return g.cocc_bits;
+    for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) lds_words[i] = g.cocc_bits[i];
+    __syncthreads();
+    return lds_words;
+}
+
 // Per-lane search state that lives beside the Walker: the ray in the space the tests run in and the best hit.
 struct LaneSearch {
-    f3 Or, Dr;
     bool found;
     float best_t;
     int best_prim;
@@ -263,14 +277,7 @@ template <int MODE, bool SINGLE_XF, bool COUNT>
 __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, WaveLds& l, Walker<MODE>& w, LaneSearch& r, f3 O, f3 D,
                                           float t_limit, WorkCounters& wc) {
     w.init(g, O, D, t_limit, true);
-    if (COUNT) wc.rays++;
-    r.Or = O;
-    r.Dr = D;
-    if (SINGLE_XF) {
-        r.Or = mul_point(sc.xinv, O);
-        r.Dr = mul_dir(sc.xinv, D);
-        if (COUNT) wc.xform_evals++;
-    }
+    if (COUNT) { wc.rays++; if (SINGLE_XF) wc.xform_evals++; }
     r.found = false;
     r.best_t = FLT_MAX;
     r.best_prim = -1;
@@ -281,19 +288,26 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
 // candidate pairs of all lanes are tested by all lanes, and each lane folds its result into its walk.
 // any_hit is per lane.  Must be called by all 64 lanes in convergent control flow.
 template <int MODE, bool SINGLE_XF, bool COUNT>
-__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, WaveLds& l, Walker<MODE>& w,
-                                           LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
+__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, WaveLds& l,
+                                           Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
     const int lane = lane_id();
     int start = 0, count = 0;
     if (COUNT) wc.w_rounds++;
-    const bool pending = w.template walk<COUNT>(g, sp, budget, start, count, r.found, r.best_t, wc);
+    const bool pending = w.template walk<COUNT>(g, sp, occ, budget, start, count, r.found, r.best_t, wc);
     if (!pending) count = 0;
     const int incl = wave_inclusive_scan(count);
-    const int total = __shfl(incl, 63);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     if (total > 0) {
         const int excl = incl - count;
-        l.ray_a[lane] = make_float4(r.Or.x, r.Or.y, r.Or.z, w.t_exit);
-        l.ray_b[lane] = make_float4(r.Dr.x, r.Dr.y, r.Dr.z, as_float(start - excl));
+        // the ray in the space the tests run in: with a single transform in the scene it is taken to object space
+        // here, once per round, instead of being kept in registers (same arithmetic, same bits every time)
+        f3 Or = w.O, Dr = w.D;
+        if (SINGLE_XF) {
+            Or = mul_point(sc.xinv, w.O);
+            Dr = mul_dir(sc.xinv, w.D);
+        }
+        l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, w.t_exit);
+        l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, as_float(start - excl));
         l.pre[lane] = excl;
         if ((lane & 7) == 0) l.pre8[lane >> 3] = excl;
         const int* ids = MODE == RT_SEARCH_REF ? g.cids : g.fids;
@@ -323,14 +337,14 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
 // Traces the wave's 64 rays to completion (a lane without a ray passes active = false).  Returns per lane
 // whether its ray hit; t_hit / prim_hit are the accepted hit.  Must be called by all 64 lanes together.
 template <int MODE, bool ANY, bool SINGLE_XF, bool COUNT>
-__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, WaveLds& l, f3 O, f3 D, float t_limit,
-                           bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
+__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, WaveLds& l, f3 O, f3 D,
+                           float t_limit, bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
     Walker<MODE> w;
     LaneSearch r;
     w.init(g, O, D, t_limit, false);
-    r.Or = O; r.Dr = D; r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
+    r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
     if (active) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, t_limit, wc);
-    while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
+    while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
     t_hit = r.best_t;
     prim_hit = r.best_prim;
     return w.hit;
