@@ -480,7 +480,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
 // ---------------------------------------------------------------------------------------------------
 #define RTX_LDS_LEVELS 6              // paths up to this many levels keep their per-level terms in LDS
 
-template <int MODE, bool SINGLE_XF, bool COUNT>
+template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS>
 __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
             if (exhausted && !__any(pix >= 0)) break;
         }
-        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, l, w, r, phase != 0, f.walk_budget, wc);
+        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, l, w, r, phase != 0, f.walk_budget, wc);
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
     if (COUNT) flush_work(wc, f.work);
@@ -747,17 +747,65 @@ __device__ __forceinline__ void cell_range(const BinParams& bp, const float* box
     }
 }
 
+// Conservative triangle / box overlap by separating axes (nine edge-cross-axis directions and the triangle's plane;
+// the three box axes are covered by the caller's cell range).  c = box centre, h = half extent already grown by the
+// binning margin, which is orders of magnitude above the rounding of this test, so a triangle that touches the
+// un-grown cell is never rejected.
+__device__ __forceinline__ bool tri_box_overlap(f3 c, f3 h, f3 a, f3 b, f3 cc) {
+    const f3 v0 = a - c, v1 = b - c, v2 = cc - c;
+    const f3 e[3] = {v1 - v0, v2 - v1, v0 - v2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f3 ed = e[k];
+        // axis (0, -ez, ey)
+        float p0 = ed.y * v0.z - ed.z * v0.y, p1 = ed.y * v1.z - ed.z * v1.y, p2 = ed.y * v2.z - ed.z * v2.y;
+        float rad = fabsf(ed.z) * h.y + fabsf(ed.y) * h.z;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+        // axis (ez, 0, -ex)
+        p0 = ed.z * v0.x - ed.x * v0.z; p1 = ed.z * v1.x - ed.x * v1.z; p2 = ed.z * v2.x - ed.x * v2.z;
+        rad = fabsf(ed.z) * h.x + fabsf(ed.x) * h.z;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+        // axis (-ey, ex, 0)
+        p0 = ed.x * v0.y - ed.y * v0.x; p1 = ed.x * v1.y - ed.y * v1.x; p2 = ed.x * v2.y - ed.y * v2.x;
+        rad = fabsf(ed.y) * h.x + fabsf(ed.x) * h.y;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+    }
+    const f3 nrm = cross3(e[0], e[1]);
+    const float d = dot3(nrm, v0);
+    const float r = h.x * fabsf(nrm.x) + h.y * fabsf(nrm.y) + h.z * fabsf(nrm.z);
+    return fabsf(d) <= r;
+}
+
 // pass 1 (FILL = false): count references per cell; pass 2 (FILL = true): scatter primitive ids,
-// Grid::placeIntoGrid (src/grid.h:76-88) for every primitive at once
+// Grid::placeIntoGrid (src/grid.h:76-88) for every primitive at once.  With geom != nullptr (nested grid only) a
+// triangle is referenced only by the cells of its box range that the triangle itself overlaps.
 template <bool FILL>
-__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids) {
+__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids,
+                      const float* geom, const int* kind, const int* xform, const float* xfwd) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     int c0[3], c1[3];
     cell_range(bp, boxes + 6 * i, c0, c1);
+    bool exact = false;
+    f3 wa = mk(0, 0, 0), wb = wa, wc = wa, cellsz = wa, half = wa;
+    if (geom != nullptr && kind[i] == RTX_PRIM_TRIANGLE && (c1[0] > c0[0] || c1[1] > c0[1] || c1[2] > c0[2])) {
+        const float* gp = geom + 9 * i;
+        const float* m = xfwd + 16 * xform[i];
+        wa = mul_point(m, mk(gp[0], gp[1], gp[2]));
+        wb = mul_point(m, mk(gp[3], gp[4], gp[5]));
+        wc = mul_point(m, mk(gp[6], gp[7], gp[8]));
+        cellsz = mk(bp.size.x / bp.res.x, bp.size.y / bp.res.y, bp.size.z / bp.res.z);
+        half = mk(0.5f * cellsz.x + bp.pad, 0.5f * cellsz.y + bp.pad, 0.5f * cellsz.z + bp.pad);
+        exact = true;
+    }
     for (int z = c0[2]; z <= c1[2]; z++)
         for (int y = c0[1]; y <= c1[1]; y++)
             for (int x = c0[0]; x <= c1[0]; x++) {
+                if (exact) {
+                    const f3 centre = mk(bp.lo.x + ((float)x + 0.5f) * cellsz.x, bp.lo.y + ((float)y + 0.5f) * cellsz.y,
+                                         bp.lo.z + ((float)z + 0.5f) * cellsz.z);
+                    if (!tri_box_overlap(centre, half, wa, wb, wc)) continue;
+                }
                 int cell;
                 if (bp.sub > 0) {
                     const int cx = x / bp.sub, cy = y / bp.sub, cz = z / bp.sub;
@@ -898,6 +946,7 @@ struct rtx_ctx {
     // scene
     bool have_scene = false;
     int n_prims = 0, n_xforms = 0, n_materials = 0, n_lights = 0;
+    int n_triangles = 0, n_spheres = 0;
     DevBuf<float4> prims, tri_normal;
     DevBuf<float> xinv, xfwd, mats, lights, geom;
     DevBuf<int> kind, xform;
@@ -1029,16 +1078,26 @@ void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level
     if (timed) (void)hipEventRecord(ev[2], st);
 }
 
+template <int MODE, bool SINGLE_XF, int PRIMS>
+void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
+    float4* ps = c->path_stack.p;
+    if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+    else hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, false, PRIMS>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+}
+
+// picks the kernel specialisation for the scene: one transform or many, triangles only / spheres only / both
 template <int MODE>
 void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
     const bool single = c->n_xforms == 1;
-    float4* ps = c->path_stack.p;
+    const int prims = c->n_spheres == 0 ? 1 : (c->n_triangles == 0 ? 2 : 0);
     if (single) {
-        if (count) hipLaunchKernelGGL((k_frame<MODE, true, true>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
-        else hipLaunchKernelGGL((k_frame<MODE, true, false>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, blocks, st, count, levels);
+        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, blocks, st, count, levels);
+        else launch_frame3<MODE, true, 0>(c, sc, f, blocks, st, count, levels);
     } else {
-        if (count) hipLaunchKernelGGL((k_frame<MODE, false, true>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
-        else hipLaunchKernelGGL((k_frame<MODE, false, false>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, blocks, st, count, levels);
+        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, blocks, st, count, levels);
+        else launch_frame3<MODE, false, 0>(c, sc, f, blocks, st, count, levels);
     }
 }
 
@@ -1189,6 +1248,9 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene_view* v) {
     }
     if (v->n_xforms > 0) HIP_TRY(hipMemcpy(c->xfwd.p, v->xforms, 16 * (size_t)v->n_xforms * sizeof(float), hipMemcpyHostToDevice));
     c->n_prims = n;
+    c->n_triangles = 0;
+    for (int i = 0; i < n; i++) c->n_triangles += v->prim_kind[i] == RTX_PRIM_TRIANGLE;
+    c->n_spheres = n - c->n_triangles;
     c->n_xforms = v->n_xforms;
     c->n_materials = v->n_materials;
     c->n_lights = v->n_lights;
@@ -1208,14 +1270,20 @@ static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevB
     if ((rc = start.reserve((size_t)n_cells + 1)) || (rc = c->cell_tmp.reserve((size_t)n_cells + 1))) return rc;
     HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_cells + 1) * sizeof(int), 0));
     const int pb = (n + 255) / 256;
-    if (n > 0) hipLaunchKernelGGL((k_bin<false>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)nullptr, (int*)nullptr);
+    const bool exact = bp.sub > 0;   // nested grid: triangles are binned by their own extent, not their box
+    const float* eg = exact ? c->geom.p : nullptr;
+    if (n > 0)
+        hipLaunchKernelGGL((k_bin<false>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)nullptr, (int*)nullptr, eg,
+                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_cells, c->cell_tmp.p, start.p);
     int total = 0;
     HIP_TRY(hipMemcpy(&total, start.p + n_cells, sizeof(int), hipMemcpyDeviceToHost));
     if (total < 0) { rtx_set_error("cell reference count overflowed 2^31"); return RTX_E_LIMIT; }
     if ((rc = ids.reserve((size_t)std::max(total, 1))) || (rc = c->scratch_ids.reserve((size_t)std::max(total, 1)))) return rc;
     HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_cells + 1) * sizeof(int), 0));
-    if (n > 0) hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p);
+    if (n > 0)
+        hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p, eg,
+                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
     hipLaunchKernelGGL(k_sort_small, dim3((n_cells + 255) / 256), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
     hipLaunchKernelGGL(k_sort_large, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, c->scratch_ids.p, 24);
     HIP_TRY(hipGetLastError());
@@ -1382,7 +1450,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const size_t pixels = (size_t)nl * p->width;
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
-    const int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the work cursors balance the rest
+    int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the work cursors balance the rest
+    if (const char* e = getenv("RTX_BLOCKS_PER_CU")) blocks = c->n_cus * std::max(1, atoi(e));   // tuning knob
     if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
     } else {

@@ -227,7 +227,7 @@ struct Walker {
 // One test of pair (owner ray, primitive).  SINGLE_XF: the scene has exactly one transform and the LDS holds the
 // ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed by its
 // primitive's inverse here (src/geometries.h:179-180).
-template <bool SINGLE_XF, bool COUNT>
+template <bool SINGLE_XF, bool COUNT, int PRIMS>
 __device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, int pid,
                                           WorkCounters& wc) {
     const float4 q0 = sc.prims[3 * pid], q1 = sc.prims[3 * pid + 1], q2 = sc.prims[3 * pid + 2];
@@ -240,7 +240,8 @@ __device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int ow
     }
     float t;
     bool ok;
-    if (as_int(q2.w) == RT_KIND_TRI) {
+    // PRIMS: 1 = the scene holds only triangles, 2 = only spheres (the other test is compiled out), 0 = both
+    if (PRIMS == 1 || (PRIMS == 0 && as_int(q2.w) == RT_KIND_TRI)) {
         if (COUNT) wc.tri_tests++;
         ok = hit_triangle(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), Oo, Do, t);
     } else {
@@ -287,7 +288,7 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
 // One round for the whole wave: every lane with an unfinished ray walks to its next candidate list, the
 // candidate pairs of all lanes are tested by all lanes, and each lane folds its result into its walk.
 // any_hit is per lane.  Must be called by all 64 lanes in convergent control flow.
-template <int MODE, bool SINGLE_XF, bool COUNT>
+template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS = 0>
 __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, WaveLds& l,
                                            Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
     const int lane = lane_id();
@@ -322,7 +323,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
                 const int owner = 8 * grp + (ha.y <= p) + (ha.z <= p) + (ha.w <= p) + (hb.x <= p) + (hb.y <= p) + (hb.z <= p) + (hb.w <= p);
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
                 const int pid = ids[as_int(rb.w) + p];
-                test_pair<SINGLE_XF, COUNT>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, pid, wc);
+                test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, pid, wc);
             }
         }
     }
