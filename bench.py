@@ -71,6 +71,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
     ap.add_argument("--cpu-row-step", type=int, default=8)
+    # rehearsal of the multi-rank control flow on a machine with fewer GPUs than ranks: collectives over gloo on
+    # host copies, every rank rendering on GPU 0; never used for reported numbers
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--share-gpu", action="store_true")
+    ap.add_argument("--check-image", action="store_true", help="rank 0 also renders the whole frame alone and compares")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -83,11 +88,17 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the renderer has no CPU path", file=sys.stderr)
         sys.exit(2)
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host_gather = args.backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if host_gather:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, depth = args.width, args.height, args.max_depth
     search = rt.SEARCH_NESTED if args.search == "nested" else rt.SEARCH_REFERENCE_LISTS
@@ -96,13 +107,15 @@ def main():
     r.set_scene(sr)
     gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
 
-    fg = FrameGather(H, W, 3, args.tile_rows, rank, world, dev)
-    local = fg.local_view()
+    fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev)
+    local = torch.empty_like(fg.local_view(), device=dev) if host_gather else fg.local_view()
     stream = torch.cuda.current_stream().cuda_stream
 
     def frame(want_stats=False, count=False, mode=search):
         st = r.render_device(local.data_ptr(), 0, W, H, depth, mode, args.tile_rows, rank, world, stream=stream,
                              want_stats=want_stats, count_work=count)
+        if host_gather:
+            fg.local_view().copy_(local)
         img = fg.gather()
         return st, img
 
@@ -121,7 +134,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -134,7 +147,7 @@ def main():
         kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
     kern = np.median(np.array(kern), axis=0)
     rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays],
-                              dtype=torch.float64, device=dev)
+                              dtype=torch.float64, device="cpu" if host_gather else dev)
     if world > 1:
         dist.all_reduce(rays_local)
     rays = [int(v) for v in rays_local.tolist()]
@@ -201,6 +214,13 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.scene, W, H, depth, args.cpu_row_step // 2, args.cpu_row_step)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if args.check_image:
+        _, img = frame()
+        if rank == 0:
+            whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            r.render_device(whole.data_ptr(), 0, W, H, depth, search, args.tile_rows, 0, 1, stream=stream)
+            torch.cuda.synchronize()
+            out["image_check"] = bool(torch.equal(img.to(dev), whole))
     if rank == 0:
         print(json.dumps(out))
     r.close()

@@ -26,7 +26,8 @@ def max_rows_per_rank(height, tile_rows, world):
 
 class FrameGather:
     """Pre-allocates the padded send/receive buffers and the row permutation for one image geometry, so that a
-    frame costs one collective and one index_copy on rank 0."""
+    frame costs one collective and one gather-by-index kernel on rank 0 (nothing at all on a single rank, whose
+    rows already are the frame)."""
 
     def __init__(self, height, width, channels, tile_rows, rank, world, device, dtype=torch.float32):
         self.h, self.w, self.c = height, width, channels
@@ -37,11 +38,16 @@ class FrameGather:
         self.send = torch.zeros((self.pad_rows, width, channels), dtype=dtype, device=device)
         self.recv = None
         self.full = None
-        if rank == 0:
-            self.recv = [torch.zeros_like(self.send) for _ in range(world)]
+        if rank == 0 and world > 1:
+            self.recv = torch.zeros((world, self.pad_rows, width, channels), dtype=dtype, device=device)
+            self.recv_list = list(self.recv.unbind(0))          # contiguous views, one per rank
             self.full = torch.zeros((height, width, channels), dtype=dtype, device=device)
-            self.row_index = [torch.as_tensor(rank_rows(height, tile_rows, r, world), device=device)
-                              for r in range(world)]
+            # image row y comes from row src[y] of the receive buffer seen as [world * pad_rows, W, C]
+            src = np.zeros(height, np.int64)
+            for r in range(world):
+                rows = rank_rows(height, tile_rows, r, world)
+                src[rows] = r * self.pad_rows + np.arange(len(rows))
+            self.src_index = torch.as_tensor(src, device=device)
 
     def local_view(self):
         """The part of the send buffer the renderer writes: [n_local_rows, W, C], contiguous."""
@@ -50,12 +56,9 @@ class FrameGather:
     def gather(self):
         """Gathers all ranks' rows; returns the assembled [H, W, C] image on rank 0, None elsewhere."""
         if self.world == 1:
-            self.full.index_copy_(0, self.row_index[0], self.send[:self.n_local])
-            return self.full
-        dist.gather(self.send, self.recv if self.rank == 0 else None, dst=0)
+            return self.send[:self.n_local]                     # one rank owns every row, in order
+        dist.gather(self.send, self.recv_list if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
-        for r in range(self.world):
-            idx = self.row_index[r]
-            self.full.index_copy_(0, idx, self.recv[r][:len(idx)])
+        torch.index_select(self.recv.view(self.world * self.pad_rows, self.w, self.c), 0, self.src_index, out=self.full)
         return self.full

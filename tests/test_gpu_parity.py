@@ -276,3 +276,22 @@ def test_general_grid_resolution(renderer):
     renderer.build_grid((9, 20, 5), 2)
     rgb, ids, _ = renderer.render(160, 120)
     assert (ids != base_ids).mean() < 1e-3
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's multi-rank control flow with two processes sharing the one GPU (collectives over gloo on host
+    copies): tiles split, gathered and reassembled frame equals the single-rank frame, ray counts add up."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "640",
+           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["image_check"] is True and out["scaling"] == "strong"
+    assert out["config"]["rays_per_frame"]["primary"] == 640 * 360
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
