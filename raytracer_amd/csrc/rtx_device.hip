@@ -350,6 +350,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, D
     WaveLds& l = lds[threadIdx.x >> 6];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const unsigned* occ = stage_occupancy(g, occ_lds);
+    const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     WorkCounters wc = {};
     const int lane = wave_lane();
     const int n = (level == 0) ? f.n_items0 : f.counters[CNT_HITS + level - 1];
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, D
         const f3 Dn = normalize3(D);
         float t = 0;
         int prim = -1;
-        const bool hit = trace_wave<MODE, false, SINGLE_XF, COUNT>(sc, g, sp, occ, l, O, Dn, FLT_MAX, active, t, prim, wc);
+        const bool hit = trace_wave<MODE, false, SINGLE_XF, COUNT>(sc, g, sp, occ, xf, l, O, Dn, FLT_MAX, active, t, prim, wc);
         const int slot = wave_alloc(f.counters + CNT_HITS + level, hit);
         if (hit) {
             if (COUNT) wc.nearest_hits++;
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
     WaveLds& l = lds[threadIdx.x >> 6];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const unsigned* occ = stage_occupancy(g, occ_lds);
+    const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     WorkCounters wc = {};
     const int lane = wave_lane();
     const int n = f.counters[CNT_HITS + level];
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
             const float tL = point ? dot3(lpos - P, L) : FLT_MAX;
             float t;
             int prim;
-            const bool occluded = trace_wave<MODE, true, SINGLE_XF, COUNT>(sc, g, sp, occ, l, So, L, tL, active, t, prim, wc);
+            const bool occluded = trace_wave<MODE, true, SINGLE_XF, COUNT>(sc, g, sp, occ, xf, l, So, L, tL, active, t, prim, wc);
             if (active && !occluded) {
                 if (COUNT) wc.light_evals++;
                 const f3 c = light_term(rayDir, L, N, kd, ks, shininess, lcol);
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const unsigned* occ = stage_occupancy(g, occ_lds);
+    const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
             if (exhausted && !__any(pix >= 0)) break;
         }
-        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, l, w, r, phase != 0, f.walk_budget, wc);
+        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
     if (COUNT) flush_work(wc, f.work);

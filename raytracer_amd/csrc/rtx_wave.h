@@ -33,13 +33,21 @@ struct __attribute__((aligned(16))) WaveLds {
     float4 ray_a[64];              // ray origin xyz (in the space the tests run in), acceptance bound t < w
     float4 ray_b[64];              // ray direction xyz, w = bits of (list start - exclusive prefix)
     unsigned long long best[64];   // (t bits << 32) | primitive, all ones = none
-    int pre[64];                   // exclusive prefix sum of the lanes' candidate counts
-    int pre8[8];                   // pre[0], pre[8], ..., pre[56]
+    int owner_at[64];              // per pair slot of the current 64-pair batch: lane whose list starts there, else 0
 };
 
 #define RT_BEST_NONE 0xffffffffffffffffull
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Orders LDS traffic between the lanes of one wave.  The lanes run in lockstep, but to the compiler every lane
+// is an independent thread: without a fence it may forward a lane's own store to its later load of the same
+// address even though another lane wrote there in between.  Wavefront scope costs no cross-wave traffic.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS round trips): four shifted
 // adds inside each row of 16 lanes, then the totals of rows 0 and 2 are broadcast into rows 1 and 3 (row_bcast:15,
@@ -266,6 +274,43 @@ __device__ __forceinline__ const unsigned* stage_occupancy(const DevGrid& g, uns
     return lds_words;
 }
 
+// Rows 0..2 of the scene's only inverse transform, read once per kernel and held in scalar registers
+// (SINGLE_XF kernels): the object-space ray of a lane is then 33 VALU operations on registers whenever needed.
+struct XfRegs {
+    float m[12];   // m[4 * col + row], row < 3
+};
+__device__ __forceinline__ XfRegs load_xf_regs(const float* xinv, bool use) {
+    XfRegs x;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            x.m[3 * c + r] = use ? as_float(__builtin_amdgcn_readfirstlane(as_int(xinv[4 * c + r]))) : 0.0f;
+    return x;
+}
+// same operation order as mul_point / mul_dir
+__device__ __forceinline__ f3 xf_point(const XfRegs& x, f3 v) {
+    return mk((x.m[0] * v.x + x.m[3] * v.y) + (x.m[6] * v.z + x.m[9] * 1.0f),
+              (x.m[1] * v.x + x.m[4] * v.y) + (x.m[7] * v.z + x.m[10] * 1.0f),
+              (x.m[2] * v.x + x.m[5] * v.y) + (x.m[8] * v.z + x.m[11] * 1.0f));
+}
+__device__ __forceinline__ f3 xf_dir(const XfRegs& x, f3 v) {
+    return mk((x.m[0] * v.x + x.m[3] * v.y) + (x.m[6] * v.z + x.m[9] * 0.0f),
+              (x.m[1] * v.x + x.m[4] * v.y) + (x.m[7] * v.z + x.m[10] * 0.0f),
+              (x.m[2] * v.x + x.m[5] * v.y) + (x.m[8] * v.z + x.m[11] * 0.0f));
+}
+
+// Inclusive running maximum over the 64 lanes (same data-parallel-primitive pattern as the prefix sum; values >= 0)
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 // Per-lane search state that lives beside the Walker: the ray in the space the tests run in and the best hit.
 struct LaneSearch {
     bool found;
@@ -288,9 +333,14 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
 // One round for the whole wave: every lane with an unfinished ray walks to its next candidate list, the
 // candidate pairs of all lanes are tested by all lanes, and each lane folds its result into its walk.
 // any_hit is per lane.  Must be called by all 64 lanes in convergent control flow.
+//
+// Pair p of the round belongs to the lane with the largest exclusive prefix <= p.  Per batch of 64 pairs each
+// lane whose list starts inside the batch writes its lane number at the slot of its first pair; a running
+// maximum over the slots (owners ascend with the slots), seeded with the owner carried over from the previous
+// batch, gives every slot its owner.
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS = 0>
-__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, WaveLds& l,
-                                           Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
+__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, const XfRegs& xf,
+                                           WaveLds& l, Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
     const int lane = lane_id();
     int start = 0, count = 0;
     if (COUNT) wc.w_rounds++;
@@ -301,32 +351,33 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     if (total > 0) {
         const int excl = incl - count;
         // the ray in the space the tests run in: with a single transform in the scene it is taken to object space
-        // here, once per round, instead of being kept in registers (same arithmetic, same bits every time)
+        // here, once per round, from the matrix held in scalar registers (same arithmetic, same bits every time)
         f3 Or = w.O, Dr = w.D;
         if (SINGLE_XF) {
-            Or = mul_point(sc.xinv, w.O);
-            Dr = mul_dir(sc.xinv, w.D);
+            Or = xf_point(xf, w.O);
+            Dr = xf_dir(xf, w.D);
         }
         l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, w.t_exit);
         l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, as_float(start - excl));
-        l.pre[lane] = excl;
-        if ((lane & 7) == 0) l.pre8[lane >> 3] = excl;
         const int* ids = MODE == RT_SEARCH_REF ? g.cids : g.fids;
+        int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
         for (int base = 0; base < total; base += 64) {
             if (COUNT) wc.w_test_batches++;
+            l.owner_at[lane] = 0;
+            wave_lds_sync();
+            if (count > 0 && excl >= base && excl < base + 64) l.owner_at[excl - base] = lane;
+            wave_lds_sync();                         // also publishes ray_a / ray_b before the first batch reads them
+            const int owner = max(wave_inclusive_max(l.owner_at[lane]), carry);
+            carry = __builtin_amdgcn_readlane(owner, 63);
             const int p = base + lane;
             if (p < total) {
-                // owner = last lane whose exclusive prefix is <= p: two 8-way steps over the sorted prefixes
-                const int4 ga = *(const int4*)&l.pre8[0], gb = *(const int4*)&l.pre8[4];
-                const int grp = (ga.y <= p) + (ga.z <= p) + (ga.w <= p) + (gb.x <= p) + (gb.y <= p) + (gb.z <= p) + (gb.w <= p);
-                const int4 ha = *(const int4*)&l.pre[8 * grp], hb = *(const int4*)&l.pre[8 * grp + 4];
-                const int owner = 8 * grp + (ha.y <= p) + (ha.z <= p) + (ha.w <= p) + (hb.x <= p) + (hb.y <= p) + (hb.z <= p) + (hb.w <= p);
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
                 const int pid = ids[as_int(rb.w) + p];
                 test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, pid, wc);
             }
         }
     }
+    wave_lds_sync();                                 // the atomic minima of all lanes land before the owners read them
     if (pending) {
         const unsigned long long b = l.best[lane];
         r.found = b != RT_BEST_NONE;
@@ -338,14 +389,14 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
 // Traces the wave's 64 rays to completion (a lane without a ray passes active = false).  Returns per lane
 // whether its ray hit; t_hit / prim_hit are the accepted hit.  Must be called by all 64 lanes together.
 template <int MODE, bool ANY, bool SINGLE_XF, bool COUNT>
-__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, WaveLds& l, f3 O, f3 D,
-                           float t_limit, bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
+__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, const XfRegs& xf, WaveLds& l,
+                           f3 O, f3 D, float t_limit, bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
     Walker<MODE> w;
     LaneSearch r;
     w.init(g, O, D, t_limit, false);
     r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
     if (active) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, t_limit, wc);
-    while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
+    while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, xf, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
     t_hit = r.best_t;
     prim_hit = r.best_prim;
     return w.hit;
