@@ -108,15 +108,16 @@ def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
     assert (ids_ref[rows] >= 0).mean() > 0.2
 
 
-@pytest.mark.parametrize("depth", [0, 1, 3])
+@pytest.mark.parametrize("depth", [0, 1, 3, 8, 15])
 def test_max_depth(renderer, depth):
     load(renderer, "scene6")
     rgb_ref, ids_ref, _, cnt = RefScene(scene_path("scene6"), counting=True).render(96, 72, depth)
-    rgb, ids, st = renderer.render(96, 72, depth, rt.SEARCH_NESTED)
-    assert_image_parity(rgb, ids, rgb_ref, ids_ref)
-    assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
-    if depth == 0:
-        assert st.reflection_rays == 0
+    for kw in PIPELINES.values():      # depths above 5 keep the per-level terms in global memory instead of LDS
+        rgb, ids, st = renderer.render(96, 72, depth, rt.SEARCH_NESTED, **kw)
+        assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+        assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+        if depth == 0:
+            assert st.reflection_rays == 0
 
 
 @pytest.mark.parametrize("w,h", [(37, 23), (1, 1), (8, 8), (9, 65), (641, 3)])
@@ -295,3 +296,29 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["image_check"] is True and out["scaling"] == "strong"
     assert out["config"]["rays_per_frame"]["primary"] == 640 * 360
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_many_lights_and_mixed_primitives(renderer, tmp_path):
+    """Four lights of both kinds with attenuation, spheres and triangles under different transforms, mirror materials."""
+    text = ("size 96 72\ncamera 0 2 9 0 0.5 0 0 1 0 40\nambient .05 .05 .05\n"
+            "attenuation 1 0.05 0.01\npoint 4 5 3 .6 .5 .4\npoint -5 3 2 .2 .4 .6\nattenuation 1 0 0\npoint 0 8 -2 .3 .3 .3\n"
+            "directional 1 1 1 .2 .2 .2\n"
+            "vertex -6 0 -6\nvertex 6 0 -6\nvertex 6 0 6\nvertex -6 0 6\n"
+            "diffuse .5 .5 .5\nspecular .4 .4 .4\nshininess 30\ntri 0 2 1\ntri 0 3 2\n"
+            "pushTransform\ntranslate -1.5 1 0\nscale 1 1.5 1\ndiffuse .7 .2 .2\nspecular .6 .6 .6\nsphere 0 0 0 1\npopTransform\n"
+            "pushTransform\ntranslate 1.6 0.8 0.5\nrotate 0 1 0 30\ndiffuse .2 .6 .3\nshininess 5\nsphere 0 0 0 .8\n"
+            "vertex -1 1 -1\nvertex 1 1 -1\nvertex 0 2.5 -1\nemission .1 .1 0\ntri 4 5 6\npopTransform\n")
+    path = tmp_path / "lights.test"
+    path.write_text(text)
+    ref = RefScene(str(path), counting=True)
+    rgb_ref, ids_ref, _, cnt = ref.render(0, 0, 5)
+    sr = rt.SceneReader().readScene(str(path))
+    assert len(sr.lights) == 4
+    renderer.set_scene(sr)
+    renderer.build_grid(15, 3)
+    for mode in MODES:
+        for kw in PIPELINES.values():
+            rgb, ids, st = renderer.render(0, 0, 5, mode, **kw)
+            assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    assert (ids_ref >= 0).mean() > 0.3 and len(np.unique(ids_ref)) >= 5
