@@ -63,8 +63,10 @@ struct DevFrame {
     int W, H;                      // full image
     int n_local_rows;              // rows this rank renders
     int tile_rows, rank, world;
-    int nbx;                       // 8-pixel column blocks per row
-    int n_items0;                  // level-0 work items (8x8 pixel blocks * 64)
+    int nbx;                       // 8-pixel column blocks per row inside the traced window
+    int bx0;                       // first 8-pixel column block of the traced window
+    int lr0;                       // first local row of the traced window (a multiple of 8)
+    int n_items0;                  // level-0 work items (8x8 pixel blocks of the traced window * 64)
     int max_depth;
     float bias;
     int walk_budget;               // persistent kernel: walk steps a lane may take per round
@@ -161,8 +163,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace(DevScene sc, DevGrid g, Dev
         if (level == 0) {
             // 64 consecutive work items = one 8x8 pixel block, so a wave's rays stay spatially coherent
             const int blk = i >> 6, in = i & 63;
-            const int lr = 8 * (blk / f.nbx) + (in >> 3);
-            const int x = 8 * (blk % f.nbx) + (in & 7);
+            const int lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
+            const int x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
             active = active && lr < f.n_local_rows && x < f.W;
             if (active) {
                 const int tile = lr / f.tile_rows;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, D
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     WaveLds& l = lds[threadIdx.x >> 6];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
-    const unsigned* occ = stage_occupancy(g, occ_lds);
+    const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     WorkCounters wc = {};
     const int lane = wave_lane();
@@ -363,8 +365,8 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_trace_w(DevScene sc, DevGrid g, D
         int pix = -1;
         if (level == 0) {
             const int blk = i >> 6, in = i & 63;
-            const int lr = 8 * (blk / f.nbx) + (in >> 3);
-            const int x = 8 * (blk % f.nbx) + (in & 7);
+            const int lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
+            const int x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
             active = active && lr < f.n_local_rows && x < f.W;
             if (active) {
                 const int tile = lr / f.tile_rows;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(RTX_BLOCK) void k_shade_w(DevScene sc, DevGrid g, D
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     WaveLds& l = lds[threadIdx.x >> 6];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
-    const unsigned* occ = stage_occupancy(g, occ_lds);
+    const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     WorkCounters wc = {};
     const int lane = wave_lane();
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
-    const unsigned* occ = stage_occupancy(g, occ_lds);
+    const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 if (path_end) {
                     f3 C = mk(0, 0, 0);
                     for (int d = top; d >= 0; d--) {
-                        const float4 s4 = stack_in_lds ? stack_lds[wave][d][lane] : stack_g[d];
+                        float4 s4;
+                        if (stack_in_lds) s4 = stack_lds[wave][d][lane]; else s4 = stack_g[d];   // one address space per load
                         const float* m = sc.mats + 16 * as_int(s4.w);
                         C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
                     }
@@ -605,8 +608,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     const int i = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
                     if (i < f.n_items0) {
                         const int blk = i >> 6, in = i & 63;
-                        const int lr = 8 * (blk / f.nbx) + (in >> 3);
-                        const int x = 8 * (blk % f.nbx) + (in & 7);
+                        const int lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
+                        const int x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
                         if (lr < f.n_local_rows && x < f.W) {
                             const int tile = lr / f.tile_rows;
                             const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
@@ -1043,6 +1046,36 @@ DevCamera make_camera(const rtx_camera* cam, int W, int H) {
     return c;
 }
 
+// Conservative pixel window [x0, x1] x [y0, y1] outside which no camera ray can meet the box [lo, hi]: the
+// bounding rectangle of the box's eight projected corners, grown by two pixels.  Any corner at or behind the eye
+// plane (or an empty scene, whose box is inverted) gives the whole frame / an empty window.  Pixel (x, y) looks
+// along a*u + b*v - w with a = tanx*((x + .5 - W/2)/(W/2)), b = tany*((H/2 - y - .5)/(H/2)) (src/geometries.h:339-351).
+void screen_window(const DevCamera& cam, f3 lo, f3 hi, int W, int H, bool have_prims, int* x0, int* x1, int* y0, int* y1) {
+    *x0 = 0; *x1 = W - 1; *y0 = 0; *y1 = H - 1;
+    if (!have_prims) { *x1 = -1; *y1 = -1; return; }          // nothing can be hit: the whole frame is the miss colour
+    if (!(lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z)) return;
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int k = 0; k < 8; k++) {
+        const double px = (k & 1) ? hi.x : lo.x, py = (k & 2) ? hi.y : lo.y, pz = (k & 4) ? hi.z : lo.z;
+        const double dx = px - cam.eye.x, dy = py - cam.eye.y, dz = pz - cam.eye.z;
+        const double depth = -(dx * cam.w.x + dy * cam.w.y + dz * cam.w.z);
+        const double extent = std::fabs(dx) + std::fabs(dy) + std::fabs(dz);
+        if (!(depth > 1e-3 * extent) || !(depth > 0)) return;   // corner beside or behind the eye: trace everything
+        const double a = (dx * cam.u.x + dy * cam.u.y + dz * cam.u.z) / depth;
+        const double b = (dx * cam.v.x + dy * cam.v.y + dz * cam.v.z) / depth;
+        const double sx = a / cam.tanx * cam.halfW + cam.halfW - 0.5;
+        const double sy = cam.halfH - 0.5 - b / cam.tany * cam.halfH;
+        if (!(sx == sx) || !(sy == sy)) return;
+        xmin = std::min(xmin, sx); xmax = std::max(xmax, sx);
+        ymin = std::min(ymin, sy); ymax = std::max(ymax, sy);
+    }
+    const double margin = 2.0;
+    *x0 = (int)std::max(0.0, std::min((double)W, std::floor(xmin - margin)));
+    *y0 = (int)std::max(0.0, std::min((double)H, std::floor(ymin - margin)));
+    *x1 = (int)std::min((double)(W - 1), std::max(-1.0, std::ceil(xmax + margin)));
+    *y1 = (int)std::min((double)(H - 1), std::max(-1.0, std::ceil(ymax + margin)));
+}
+
 int ensure_workspace(rtx_ctx* c, size_t pixels, int levels) {
     if (pixels <= c->ws_pixels && levels <= c->ws_levels) return RTX_OK;
     pixels = std::max(pixels, c->ws_pixels);
@@ -1470,15 +1503,33 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.W = p->width; f.H = p->height;
     f.n_local_rows = nl;
     f.tile_rows = tile_rows; f.rank = rank; f.world = world;
-    f.nbx = (p->width + 7) / 8;
-    f.n_items0 = f.nbx * ((nl + 7) / 8) * 64;
+    f.cam = make_camera(cam, p->width, p->height);
+    // Traced window: only pixels whose camera ray can reach the grid's box are traced; the rest of the frame is the
+    // miss colour (src/main.cpp:104-106) and is written by two fills.
+    int wx0, wx1, wy0, wy1;
+    screen_window(f.cam, c->dgrid.lo, c->dgrid.hi, p->width, p->height, c->n_prims > 0, &wx0, &wx1, &wy0, &wy1);
+    int lr_begin = 0, lr_end = 0;   // local rows of this rank with wy0 <= global row <= wy1
+    {
+        const int n_tiles = (p->height + tile_rows - 1) / tile_rows;
+        int lr = 0;
+        bool any = false;
+        for (int t = rank; t < n_tiles; t += world)
+            for (int r = 0; r < tile_rows && t * tile_rows + r < p->height; r++, lr++) {
+                const int y = t * tile_rows + r;
+                if (y >= wy0 && y <= wy1) { if (!any) { lr_begin = lr; any = true; } lr_end = lr + 1; }
+            }
+    }
+    f.lr0 = lr_begin & ~7;
+    f.bx0 = wx0 / 8;
+    f.nbx = wx1 >= wx0 ? wx1 / 8 - f.bx0 + 1 : 0;
+    f.n_items0 = f.nbx * ((lr_end - f.lr0 + 7) / 8) * 64;
+    const bool whole_frame = f.lr0 == 0 && lr_end == nl && f.bx0 == 0 && f.nbx == (p->width + 7) / 8;
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
     f.walk_budget = 2;
     f.ready_threshold = 32;
     if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
     if (const char* e = getenv("RTX_READY_THRESHOLD")) f.ready_threshold = std::max(1, atoi(e));
-    f.cam = make_camera(cam, p->width, p->height);
     f.rgb = d_rgb;
     f.ids = d_ids;
     f.counters = c->counters.p;
@@ -1489,10 +1540,15 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const bool count = (p->flags & RTX_RENDER_COUNT_WORK) != 0;
     const bool timed = stats != nullptr;
 
+    hipEvent_t* ev = c->ev;
+    HIP_TRY(hipEventRecord(ev[0], st));              // frame time includes the fills
+    if (!whole_frame) {
+        HIP_TRY(hipMemsetAsync(d_rgb, 0, pixels * 3 * sizeof(float), st));            // 0.0f
+        if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xff, pixels * sizeof(int32_t), st));   // -1
+    }
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
     if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 24 * sizeof(unsigned long long), st));
-    hipEvent_t* ev = c->ev;
-    HIP_TRY(hipEventRecord(ev[0], st));
+    HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
         if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels);
         else launch_frame<RT_SEARCH_NESTED>(c, sc, f, blocks, st, count, levels);
@@ -1544,7 +1600,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
             (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
         } else {
             stats->trace_launches = 1;                 // the persistent frame kernel does everything
-            (void)hipEventElapsedTime(&stats->trace_ms, ev[0], ev[1]);
+            (void)hipEventElapsedTime(&stats->trace_ms, ev[3], ev[1]);
         }
         if (count) {
             unsigned long long w[24];

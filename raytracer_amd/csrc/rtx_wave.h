@@ -63,6 +63,29 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     return v;
 }
 
+// Coarse-cell occupancy bits of the nested grid: staged in LDS by the whole workgroup when the grid is small enough
+// (the reference's 15^3 grid is 106 words), else read from global memory.  Returns the pointer the walkers use.
+#define RT_OCC_LDS_WORDS 128
+struct Occupancy {
+    const unsigned* lds;      // staged copy (LDS), used when global is null
+    const unsigned* global;   // set only when the grid is too large for the LDS copy
+    __device__ __forceinline__ bool test(int cell) const {
+        // two separate loads (wave-uniform choice) so that each compiles to its own address space's instruction
+        const unsigned word = global ? global[cell >> 5] : lds[cell >> 5];
+        return (word >> (cell & 31)) & 1u;
+    }
+};
+__device__ __forceinline__ Occupancy stage_occupancy(const DevGrid& g, unsigned* lds_words) {
+    Occupancy o;
+    o.lds = lds_words;
+    o.global = nullptr;
+    const int n_words = (g.rx * g.ry * g.rz + 31) >> 5;
+    if (g.cocc_bits == nullptr || n_words > RT_OCC_LDS_WORDS) { o.global = g.cocc_bits; return o; }
+    for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) lds_words[i] = g.cocc_bits[i];
+    __syncthreads();
+    return o;
+}
+
 // Per-lane walk state.  MODE = RT_SEARCH_REF: every coarse cell's reference list is a candidate list.
 // MODE = RT_SEARCH_NESTED: fine 3D-DDA inside occupied coarse cells, candidates = lists of occupied fine cells.
 // The advance steps are written with selects instead of branches: the three axes of a divergent wave would
@@ -169,7 +192,7 @@ struct Walker {
     // used `budget` steps.  Every step either finishes the ray or moves a cell index monotonically toward the
     // grid boundary, so the walk terminates.
     template <bool COUNT>
-    __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, const unsigned* occ, int budget, int& start,
+    __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, const Occupancy& occ, int budget, int& start,
                                          int& count, bool found, float best_t, WorkCounters& wc) {
         while (state != 2 && budget-- > 0) {
             if (COUNT) wc.w_walk_iters++;
@@ -181,7 +204,7 @@ struct Walker {
                     const int b = g.cstart[cell], e = g.cstart[cell + 1];
                     if (e > b) { start = b; count = e - b; return true; }
                     coarse_advance(g);
-                } else if ((occ[cell >> 5] >> (cell & 31)) & 1u) {
+                } else if (occ.test(cell)) {
                     const int k = g.sub;
                     const f3 p = O + fmaxf(t_in, 0.0f) * D;
                     const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - ix * k, 0), k - 1);
@@ -263,17 +286,6 @@ __device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int ow
     }
 }
 
-// Coarse-cell occupancy bits of the nested grid: staged in LDS by the whole workgroup when the grid is small enough
-// (the reference's 15^3 grid is 106 words), else read from global memory.  Returns the pointer the walkers use.
-#define RT_OCC_LDS_WORDS 128
-__device__ __forceinline__ const unsigned* stage_occupancy(const DevGrid& g, unsigned* lds_words) {
-    const int n_words = (g.rx * g.ry * g.rz + 31) >> 5;
-    if (g.cocc_bits == nullptr || n_words > RT_OCC_LDS_WORDS) return g.cocc_bits;
-    for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) lds_words[i] = g.cocc_bits[i];
-    __syncthreads();
-    return lds_words;
-}
-
 // Rows 0..2 of the scene's only inverse transform, read once per kernel and held in scalar registers
 // (SINGLE_XF kernels): the object-space ray of a lane is then 33 VALU operations on registers whenever needed.
 struct XfRegs {
@@ -339,7 +351,7 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
 // maximum over the slots (owners ascend with the slots), seeded with the owner carried over from the previous
 // batch, gives every slot its owner.
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS = 0>
-__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, const XfRegs& xf,
+__device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const Occupancy& occ, const XfRegs& xf,
                                            WaveLds& l, Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
     const int lane = lane_id();
     int start = 0, count = 0;
@@ -389,7 +401,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
 // Traces the wave's 64 rays to completion (a lane without a ray passes active = false).  Returns per lane
 // whether its ray hit; t_hit / prim_hit are the accepted hit.  Must be called by all 64 lanes together.
 template <int MODE, bool ANY, bool SINGLE_XF, bool COUNT>
-__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const unsigned* occ, const XfRegs& xf, WaveLds& l,
+__device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const Occupancy& occ, const XfRegs& xf, WaveLds& l,
                            f3 O, f3 D, float t_limit, bool active, float& t_hit, int& prim_hit, WorkCounters& wc) {
     Walker<MODE> w;
     LaneSearch r;
