@@ -322,3 +322,43 @@ def test_many_lights_and_mixed_primitives(renderer, tmp_path):
             assert_image_parity(rgb, ids, rgb_ref, ids_ref)
             assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
     assert (ids_ref >= 0).mean() > 0.3 and len(np.unique(ids_ref)) >= 5
+
+
+WINDOW_CAMERAS = {
+    "far_small_window": "camera 0 1 40 0 1 0 0 1 0 30",
+    "off_centre": "camera 0 1 25 6 3 0 0 1 0 35",
+    "box_leaves_the_frame": "camera 3 1 6 3 1 0 0 1 0 50",
+    "eye_inside_the_box": "camera 0 0.5 1.8 0 1 -1 0 1 0 60",
+    "box_behind_the_eye": "camera 0 1 12 0 1 30 0 1 0 40",
+    "corner_beside_the_eye": "camera 2.6 1 3 -1 1 0 0 1 0 90",
+    "rolled_and_wide": "camera 8 9 10 0 0 0 1 1 0 100",
+    "looking_straight_down": "camera 0 30 0 0 0 0 0 0 -1 25",
+}
+
+
+@pytest.mark.parametrize("cam", list(WINDOW_CAMERAS))
+@pytest.mark.parametrize("w,h", [(160, 120), (203, 77)])
+def test_screen_window_cameras(renderer, tmp_path, cam, w, h):
+    """Only the pixels that can see the grid box are traced; the rest are filled.  Cameras that make the window small,
+    clipped by the frame, empty or undefined (a box corner beside or behind the eye) must all give the oracle's frame,
+    for the whole frame and for the row tiles of three ranks."""
+    text = (f"size {w} {h}\n{WINDOW_CAMERAS[cam]}\nambient .1 .1 .1\npoint 3 6 4 .8 .8 .8\ndirectional -1 1 1 .3 .3 .3\n"
+            "vertex -2 0 -2\nvertex 2 0 -2\nvertex 2 0 2\nvertex -2 0 2\ndiffuse .5 .5 .6\nspecular .5 .5 .5\nshininess 20\n"
+            "tri 0 2 1\ntri 0 3 2\npushTransform\ntranslate 0 1 0\ndiffuse .7 .3 .2\nsphere 0 0 0 1\npopTransform\n"
+            "pushTransform\ntranslate 1.5 2.2 -1\nscale .5 .8 .5\ndiffuse .2 .7 .3\nsphere 0 0 0 1\npopTransform\n")
+    path = tmp_path / "window.test"
+    path.write_text(text)
+    rgb_ref, ids_ref, _, cnt = RefScene(str(path), counting=True).render(0, 0, 5)
+    renderer.set_scene(rt.SceneReader().readScene(str(path)))
+    renderer.build_grid(15, 0)
+    for mode in MODES:
+        for kw in PIPELINES.values():
+            rgb, ids, st = renderer.render(0, 0, 5, mode, **kw)
+            assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+    acc, acc_ids = np.full_like(rgb_ref, np.nan), np.full_like(ids_ref, -7)
+    for rank in range(3):
+        rows = rt.local_rows(h, 8, rank, 3)
+        rgb, ids, _ = renderer.render(0, 0, 5, rt.SEARCH_NESTED, 8, rank, 3)
+        acc[rows], acc_ids[rows] = rgb[rows], ids[rows]
+    assert_image_parity(acc, acc_ids, rgb_ref, ids_ref)
