@@ -170,6 +170,8 @@ typedef struct rtx_stats {
     int64_t trace_work[8], shade_work[8];
     int64_t wave_events[4];        /* wave-cooperative kernels: rounds, walk-loop iterations, 64-pair test batches,
                                       state updates -- each counted once per wave                               */
+    int64_t wave_cycles[4];        /* persistent frame kernel: shader-clock cycles summed over waves spent in state
+                                      updates, walking, pair tests, folding results (counting builds only)     */
     float   frame_ms;              /* first kernel to framebuffer complete on the device (HIP events)     */
     float   trace_ms, shade_ms, resolve_ms;   /* per kernel family, summed over levels; the persistent frame
                                                  kernel is reported as trace_ms with trace_launches = 1   */

@@ -57,7 +57,7 @@ class RenderStats(C.Structure):
                 ("tri_tests", C.c_int64), ("sphere_tests", C.c_int64), ("xform_evals", C.c_int64),
                 ("cell_steps", C.c_int64), ("fine_steps", C.c_int64), ("light_evals", C.c_int64),
                 ("nearest_hits", C.c_int64),
-                ("trace_work", C.c_int64 * 8), ("shade_work", C.c_int64 * 8), ("wave_events", C.c_int64 * 4),
+                ("trace_work", C.c_int64 * 8), ("shade_work", C.c_int64 * 8), ("wave_events", C.c_int64 * 4), ("wave_cycles", C.c_int64 * 4),
                 ("frame_ms", C.c_float), ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("resolve_ms", C.c_float),
                 ("level_trace_ms", C.c_float * 16), ("level_shade_ms", C.c_float * 16),
                 ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("resolve_launches", C.c_int32)]
@@ -67,7 +67,7 @@ class RenderStats(C.Structure):
         return self.primary_rays + self.shadow_rays + self.reflection_rays
 
     def as_dict(self):
-        arrays = ("hits_per_level", "trace_work", "shade_work", "wave_events", "level_trace_ms", "level_shade_ms")
+        arrays = ("hits_per_level", "trace_work", "shade_work", "wave_events", "wave_cycles", "level_trace_ms", "level_shade_ms")
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in arrays}
         for k in arrays:
             d[k] = list(getattr(self, k))

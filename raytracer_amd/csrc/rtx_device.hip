@@ -134,6 +134,13 @@ __device__ __forceinline__ void flush_work(const WorkCounters& wc, unsigned long
         for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
         if (wave_lane() == 0 && x) atomicAdd(out + 16 + k, x);
     }
+    const unsigned long long cy[4] = {wc.c_update, wc.c_walk, wc.c_test, wc.c_fold};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = cy[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+        if (wave_lane() == 0 && x) atomicAdd(out + 20 + k, x);
+    }
 }
 
 // Camera::getRayAt (src/geometries.h:339-351); tanx, tany, halfW, halfH are per-frame constants
@@ -515,6 +522,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
         const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(pix < 0)));
         if (!__any(walking) || n_ready >= f.ready_threshold) {
             if (COUNT) wc.w_updates++;
+            const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
             bool begin = false;
             f3 O = w.O, D = w.D;
             float tl = w.t_limit;
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 if (base + n_idle >= f.n_items0) exhausted = true;
             }
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
+            if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             if (exhausted && !__any(pix >= 0)) break;
         }
         if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
@@ -1605,7 +1614,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         if (count) {
             unsigned long long w[24];
             HIP_TRY(hipMemcpy(w, c->work.p, sizeof w, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 4; k++) stats->wave_events[k] = (int64_t)w[16 + k];
+            for (int k = 0; k < 4; k++) { stats->wave_events[k] = (int64_t)w[16 + k]; stats->wave_cycles[k] = (int64_t)w[20 + k]; }
             for (int k = 0; k < 8; k++) { stats->trace_work[k] = (int64_t)w[k]; stats->shade_work[k] = (int64_t)w[8 + k]; }
             stats->tri_tests = (int64_t)(w[0] + w[8]); stats->sphere_tests = (int64_t)(w[1] + w[9]);
             stats->xform_evals = (int64_t)(w[2] + w[10]); stats->cell_steps = (int64_t)(w[3] + w[11]);

@@ -45,6 +45,8 @@ struct WorkCounters {
     unsigned long long tri_tests, sphere_tests, xform_evals, cell_steps, fine_steps, light_evals, nearest_hits, rays;
     // wave-level events (counted once per wave): rounds, walk-loop iterations, 64-pair test batches, state updates
     unsigned long long w_rounds, w_walk_iters, w_test_batches, w_updates;
+    // shader-clock cycles a wave spent per section (counting builds only): state update, walk, pair tests, fold
+    unsigned long long c_update, c_walk, c_test, c_fold;
 };
 
 #define RT_KIND_TRI 0

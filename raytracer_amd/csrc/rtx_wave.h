@@ -356,10 +356,12 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     const int lane = lane_id();
     int start = 0, count = 0;
     if (COUNT) wc.w_rounds++;
+    const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
     const bool pending = w.template walk<COUNT>(g, sp, occ, budget, start, count, r.found, r.best_t, wc);
     if (!pending) count = 0;
     const int incl = wave_inclusive_scan(count);
     const int total = __builtin_amdgcn_readlane(incl, 63);
+    const unsigned long long c1 = COUNT ? __builtin_readcyclecounter() : 0ull;
     if (total > 0) {
         const int excl = incl - count;
         // the ray in the space the tests run in: with a single transform in the scene it is taken to object space
@@ -390,11 +392,16 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
         }
     }
     wave_lds_sync();                                 // the atomic minima of all lanes land before the owners read them
+    const unsigned long long c2 = COUNT ? __builtin_readcyclecounter() : 0ull;
     if (pending) {
         const unsigned long long b = l.best[lane];
         r.found = b != RT_BEST_NONE;
         if (r.found) { r.best_t = as_float((int)(b >> 32)); r.best_prim = (int)(b & 0xffffffffull); }
         w.after_tests(g, r.found, r.best_t, any_hit);
+    }
+    if (COUNT) {
+        const unsigned long long c3 = __builtin_readcyclecounter();
+        wc.c_walk += c1 - c0; wc.c_test += c2 - c1; wc.c_fold += c3 - c2;
     }
 }
 

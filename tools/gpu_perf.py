@@ -43,7 +43,7 @@ def run(search, serial, label, lq=True):
     same_rgb = np.array_equal(rgb.view(np.int32), base[1].view(np.int32))
     print(f"{label}: frame {t[0]:.3f} ms trace {t[1]:.3f} shade {t[2]:.3f} resolve {t[3]:.3f} | rays {st.total_rays} "
           f"Mrays/s {st.total_rays / t[0] / 1e3:.1f} | tri {st.tri_tests} sph {st.sphere_tests} cells {st.cell_steps} "
-          f"fine {st.fine_steps} | wave events (rounds, walk iters, test batches, updates) {list(st.wave_events)} | same ids {same_ids} same rgb {same_rgb}", flush=True)
+          f"fine {st.fine_steps} | wave events (rounds, walk iters, test batches, updates) {list(st.wave_events)} cycles (update, walk, test, fold) {[round(c / max(1, sum(st.wave_cycles)), 3) for c in st.wave_cycles]} | same ids {same_ids} same rgb {same_rgb}", flush=True)
     print("     per level trace ms", [round(v, 3) for v in list(s2.level_trace_ms)[:6]], "shade ms",
           [round(v, 3) for v in list(s2.level_shade_ms)[:6]], "hits", list(s2.hits_per_level)[:6], flush=True)
 
