@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--check-image", action="store_true", help="rank 0 also renders the whole frame alone and compares")
+    ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
+                    help="what travels to rank 0: the float framebuffer (Image3f, the default) or the 8-bit image the "
+                         "reference saves, converted on each GPU before the gather (a quarter of the bytes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,15 +110,22 @@ def main():
     r.set_scene(sr)
     gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
 
-    fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev)
-    local = torch.empty_like(fg.local_view(), device=dev) if host_gather else fg.local_view()
+    as_u8 = args.gather == "u8"
+    fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev,
+                     dtype=torch.uint8 if as_u8 else torch.float32)
+    # `local` receives the float rows of this rank; `staged` is what the gather sends (the same tensor unless the
+    # rows are converted to 8 bits first or the collective runs on host copies)
+    staged = torch.empty_like(fg.local_view(), device=dev) if host_gather else fg.local_view()
+    local = torch.empty(tuple(staged.shape), dtype=torch.float32, device=dev) if as_u8 else staged
     stream = torch.cuda.current_stream().cuda_stream
 
     def frame(want_stats=False, count=False, mode=search):
         st = r.render_device(local.data_ptr(), 0, W, H, depth, mode, args.tile_rows, rank, world, stream=stream,
                              want_stats=want_stats, count_work=count)
+        if as_u8:
+            r.quantize_device(local.data_ptr(), local.shape[0] * W, staged.data_ptr(), stream=stream)
         if host_gather:
-            fg.local_view().copy_(local)
+            fg.local_view().copy_(staged)
         img = fg.gather()
         return st, img
 
@@ -191,7 +201,7 @@ def main():
             "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
             "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {depth}, 15^3 grid, search={args.search}, "
                                    f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "
-                                   "gather to rank 0",
+                                   f"{args.gather} gather to rank 0",
                        "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays},
                        "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1]},
                        "grid": {"refs_reference_lists": gi.n_refs, "fine_cells": gi.n_fine_cells,
@@ -220,6 +230,11 @@ def main():
             whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
             r.render_device(whole.data_ptr(), 0, W, H, depth, search, args.tile_rows, 0, 1, stream=stream)
             torch.cuda.synchronize()
+            if as_u8:
+                whole_q = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+                r.quantize_device(whole.data_ptr(), H * W, whole_q.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                whole = whole_q
             out["image_check"] = bool(torch.equal(img.to(dev), whole))
     if rank == 0:
         print(json.dumps(out))

@@ -210,6 +210,14 @@ int  rtx_camera_rays(rtx_ctx* ctx, const rtx_camera* cam, int32_t width, int32_t
  * Conversion to 8 bits truncates, (unsigned char)(clamp(c) * 255), as the reference does (:72-74,163-165).
  * ---------------------------------------------------------------------------------------------- */
 int  rtx_quantize(const float* rgb, int64_t n_values, uint8_t* out);
+/* The same conversion on the device, asynchronous on `stream` (a hipStream_t, NULL = default stream): d_rgb is
+ * n_pixels*3 floats of device memory (16-byte aligned), d_out n_pixels*3 bytes of device memory (4-byte aligned).
+ * RTX_ORDER_RGB keeps the channel order (write3fPpm, :63-80); RTX_ORDER_BGR swaps red and blue inside each pixel,
+ * the layout get_3b_bgr_buffer hands to OpenCV (:154-170).  A multi-GPU run converts before the gather and so moves
+ * a quarter of the bytes. */
+#define RTX_ORDER_RGB 0
+#define RTX_ORDER_BGR 1
+int  rtx_quantize_device(rtx_ctx* ctx, const float* d_rgb, int64_t n_pixels, uint8_t* d_out, int32_t order, void* stream);
 /* Format by extension: .png (8-bit RGB, zlib deflate) or .ppm (P6). */
 int  rtx_save_image(const char* path, const float* rgb, int32_t width, int32_t height);
 

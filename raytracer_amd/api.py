@@ -19,6 +19,7 @@ GRID_REFERENCE = 1
 GRID_NESTED = 2
 RENDER_COUNT_WORK = 1
 RENDER_SERIAL_LANES = 2
+ORDER_RGB, ORDER_BGR = 0, 1
 RENDER_LEVEL_QUEUES = 4
 
 
@@ -116,6 +117,7 @@ def _load():
         "rtx_intersect": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rtx_camera_rays": (C.c_int, [vp, C.POINTER(_Camera), i32, i32, i32, vp, vp]),
         "rtx_quantize": (C.c_int, [vp, C.c_int64, vp]),
+        "rtx_quantize_device": (C.c_int, [vp, vp, C.c_int64, vp, i32, vp]),
         "rtx_save_image": (C.c_int, [C.c_char_p, vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
@@ -130,7 +132,8 @@ EXPORTED_SYMBOLS = (
     "rtx_strerror", "rtx_last_error", "rtx_scene_load", "rtx_scene_parse", "rtx_scene_free", "rtx_scene_get_view",
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
-    "rtx_render_device", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_save_image")
+    "rtx_render_device", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
+    "rtx_save_image")
 
 
 def _check(rc):
@@ -322,6 +325,11 @@ class Renderer:
                                          C.c_void_p(stream) if stream else None,
                                          C.byref(st) if st is not None else None))
         return st
+
+    def quantize_device(self, d_rgb_ptr, n_pixels, d_out_ptr, bgr=False, stream=None):
+        """Enqueues the 8-bit conversion of a DEVICE float framebuffer into DEVICE bytes (raw pointers)."""
+        _check(_load().rtx_quantize_device(self._h, C.c_void_p(d_rgb_ptr), n_pixels, C.c_void_p(d_out_ptr),
+                                           ORDER_BGR if bgr else ORDER_RGB, C.c_void_p(stream) if stream else None))
 
     def intersect(self, origins, dirs, t_limit=None, search=SEARCH_NESTED):
         O = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)

@@ -645,6 +645,50 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8-bit conversion of a float framebuffer on the device: (unsigned char)(clamp(c) * 255), truncating, as
+// Image3f::write3fPpm and get_3b_bgr_buffer do (src/Image3f.h:63-80,154-170).  Four pixels per lane: three
+// 16-byte loads, one 12-byte store.  Pure streaming, 15 bytes of traffic per pixel.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned to_u8_dev(float c) {
+    const float hi = (1.0f < c) ? 1.0f : c;          // same selects as clamp() in src/Image3f.h:15-17
+    const float v = (hi < 0.0f) ? 0.0f : hi;
+    const float s = v * 255.0f;
+    return (s == s) ? (unsigned)(int)s : 0u;         // s is in [0, 255] or NaN
+}
+
+template <bool BGR>
+__global__ __launch_bounds__(256) void k_quantize(const float* __restrict__ rgb, long long n_pixels, unsigned char* __restrict__ out) {
+    const long long n_quads = n_pixels >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += stride) {
+        const float4* src = reinterpret_cast<const float4*>(rgb) + 3 * q;
+        const float4 a = src[0], b = src[1], c = src[2];
+        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        unsigned w[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            unsigned word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * k + j;                               // output byte e of this quad
+                const int from = BGR ? 3 * (e / 3) + (2 - e % 3) : e;  // channel swap inside each pixel
+                word |= to_u8_dev(v[from]) << (8 * j);
+            }
+            w[k] = word;
+        }
+        uint3* dst = reinterpret_cast<uint3*>(out) + q;
+        *dst = make_uint3(w[0], w[1], w[2]);
+    }
+    // up to three pixels that do not fill a quad
+    const long long tail = n_quads << 2;
+    const long long i = tail + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pixels) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) out[3 * i + ch] = (unsigned char)to_u8_dev(rgb[3 * i + (BGR ? 2 - ch : ch)]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // probes (tests): single rays through the grid, camera rays
 // ---------------------------------------------------------------------------------------------------
 template <int MODE>
@@ -1721,6 +1765,28 @@ int rtx_camera_rays(rtx_ctx* c, const rtx_camera* cam, int32_t W, int32_t H, int
     if (rc) rtx_set_error("rtx_camera_rays: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
     dxy.release(); dd.release();
     return rc;
+}
+
+int rtx_quantize_device(rtx_ctx* c, const float* d_rgb, int64_t n_pixels, uint8_t* d_out, int32_t order, void* stream) {
+    if (!c || n_pixels < 0 || (n_pixels > 0 && (!d_rgb || !d_out)) || (order != RTX_ORDER_RGB && order != RTX_ORDER_BGR)) {
+        rtx_set_error("rtx_quantize_device: bad argument");
+        return RTX_E_INVALID;
+    }
+    if (((uintptr_t)d_rgb & 15u) || ((uintptr_t)d_out & 3u)) {
+        rtx_set_error("rtx_quantize_device: d_rgb must be 16-byte aligned and d_out 4-byte aligned");
+        return RTX_E_INVALID;
+    }
+    if (n_pixels == 0) return RTX_OK;
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    const long long quads = std::max<long long>(1, n_pixels >> 2);
+    const int blocks = (int)std::min<long long>((quads + 255) / 256, 256 * 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (order == RTX_ORDER_BGR) hipLaunchKernelGGL(k_quantize<true>, dim3(blocks), dim3(256), 0, st, d_rgb, (long long)n_pixels, d_out);
+    else hipLaunchKernelGGL(k_quantize<false>, dim3(blocks), dim3(256), 0, st, d_rgb, (long long)n_pixels, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rtx_set_error("rtx_quantize_device: launch failed: %s", hipGetErrorString(e)); return RTX_E_DEVICE; }
+    return RTX_OK;
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 #include "rtx_internal.h"
 
 #include <cerrno>
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,16 +53,22 @@ inline bool next_token(Cursor& c, const char*& tok, size_t& len) {
 struct Fields {
     Cursor c;
     bool failed = false;
+    // Decimal -> float, correctly rounded as the stream extraction is.  std::from_chars covers the plain
+    // decimal spellings scene files use; anything it does not take whole (a leading '+', a hexadecimal
+    // float, trailing characters) goes through strtof, whose prefix rule is the one the parser had before.
     float f() {
         const char* t;
         size_t n;
         if (failed || !next_token(c, t, n)) { failed = true; return 0.0f; }
+        float v = 0.0f;
+        const std::from_chars_result r = std::from_chars(t, t + n, v);
+        if (r.ec == std::errc() && r.ptr == t + n) return v;
         char buf[64];
         if (n >= sizeof buf) { failed = true; return 0.0f; }
         memcpy(buf, t, n);
         buf[n] = 0;
         char* e = nullptr;
-        float v = strtof(buf, &e);      // correctly rounded decimal -> float, as the stream extraction is
+        v = strtof(buf, &e);
         if (e == buf) { failed = true; return 0.0f; }
         return v;
     }
@@ -69,12 +76,15 @@ struct Fields {
         const char* t;
         size_t n;
         if (failed || !next_token(c, t, n)) { failed = true; return 0; }
+        long v = 0;
+        const std::from_chars_result r = std::from_chars(t, t + n, v, 10);
+        if (r.ec == std::errc() && r.ptr == t + n) return v;
         char buf[64];
         if (n >= sizeof buf) { failed = true; return 0; }
         memcpy(buf, t, n);
         buf[n] = 0;
         char* e = nullptr;
-        long v = strtol(buf, &e, 10);
+        v = strtol(buf, &e, 10);
         if (e == buf) { failed = true; return 0; }
         return v;
     }
@@ -117,12 +127,21 @@ int parse_text(const char* text, size_t n_bytes, rtx_scene* sc) {
         map.emplace(k, id);
         return id;
     };
+    // the current material / transform is looked up again only after a directive changed it: a mesh of
+    // 100 000 triangles under one material and one transform costs two lookups, not 200 000
+    int32_t material_id = -1, xform_id = -1;
     auto cur_material = [&]() {
-        float m[13] = {ambient[0], ambient[1], ambient[2], diffuse[0], diffuse[1], diffuse[2],
-                       specular[0], specular[1], specular[2], emission[0], emission[1], emission[2], shininess};
-        return intern(material_ids, sc->materials, m, 13);
+        if (material_id < 0) {
+            float m[13] = {ambient[0], ambient[1], ambient[2], diffuse[0], diffuse[1], diffuse[2],
+                           specular[0], specular[1], specular[2], emission[0], emission[1], emission[2], shininess};
+            material_id = intern(material_ids, sc->materials, m, 13);
+        }
+        return material_id;
     };
-    auto cur_xform = [&]() { return intern(xform_ids, sc->xforms, stack.back().m, 16); };
+    auto cur_xform = [&]() {
+        if (xform_id < 0) xform_id = intern(xform_ids, sc->xforms, stack.back().m, 16);
+        return xform_id;
+    };
 
     const char* p = text;
     const char* end = text + n_bytes;
@@ -149,9 +168,11 @@ int parse_text(const char* text, size_t n_bytes, rtx_scene* sc) {
                 return RTX_E_INVALID;
             }
             sc->prim_kind.push_back(RTX_PRIM_TRIANGLE);
-            const long idx[3] = {a, b, c};
-            for (int k = 0; k < 3; k++)
-                for (int d = 0; d < 3; d++) sc->prim_geom.push_back(verts[3 * idx[k] + d]);
+            const size_t at = sc->prim_geom.size();
+            sc->prim_geom.resize(at + 9);
+            memcpy(&sc->prim_geom[at], &verts[3 * a], 3 * sizeof(float));
+            memcpy(&sc->prim_geom[at + 3], &verts[3 * b], 3 * sizeof(float));
+            memcpy(&sc->prim_geom[at + 6], &verts[3 * c], 3 * sizeof(float));
             sc->prim_material.push_back(cur_material());
             sc->prim_xform.push_back(cur_xform());
         } else if (cmd_is(t, n, "sphere")) {
@@ -180,24 +201,27 @@ int parse_text(const char* text, size_t n_bytes, rtx_scene* sc) {
             l[8] = point ? atten[1] : 0.0f;
             l[9] = point ? atten[2] : 0.0f;
             sc->lights.insert(sc->lights.end(), l, l + 10);
-        } else if (cmd_is(t, n, "ambient")) { for (int k = 0; k < 3; k++) ambient[k] = fl.f(); }
-        else if (cmd_is(t, n, "diffuse")) { for (int k = 0; k < 3; k++) diffuse[k] = fl.f(); }
-        else if (cmd_is(t, n, "specular")) { for (int k = 0; k < 3; k++) specular[k] = fl.f(); }
-        else if (cmd_is(t, n, "emission")) { for (int k = 0; k < 3; k++) emission[k] = fl.f(); }
-        else if (cmd_is(t, n, "shininess")) { shininess = fl.f(); }
+        } else if (cmd_is(t, n, "ambient")) { for (int k = 0; k < 3; k++) ambient[k] = fl.f(); material_id = -1; }
+        else if (cmd_is(t, n, "diffuse")) { for (int k = 0; k < 3; k++) diffuse[k] = fl.f(); material_id = -1; }
+        else if (cmd_is(t, n, "specular")) { for (int k = 0; k < 3; k++) specular[k] = fl.f(); material_id = -1; }
+        else if (cmd_is(t, n, "emission")) { for (int k = 0; k < 3; k++) emission[k] = fl.f(); material_id = -1; }
+        else if (cmd_is(t, n, "shininess")) { shininess = fl.f(); material_id = -1; }
         else if (cmd_is(t, n, "attenuation")) { for (int k = 0; k < 3; k++) atten[k] = fl.f(); }
         else if (cmd_is(t, n, "pushTransform")) { stack.push_back(stack.back()); }
-        else if (cmd_is(t, n, "popTransform")) { if (stack.size() > 1) stack.pop_back(); }   // identity is unpoppable
+        else if (cmd_is(t, n, "popTransform")) { if (stack.size() > 1) stack.pop_back(); xform_id = -1; }   // identity is unpoppable
         else if (cmd_is(t, n, "translate")) {
             float x = fl.f(), y = fl.f(), z = fl.f();
             stack.back() = rt::mat_translate(stack.back(), x, y, z);
+            xform_id = -1;
         } else if (cmd_is(t, n, "rotate")) {
             float x = fl.f(), y = fl.f(), z = fl.f(), deg = fl.f();
             const float pi = 3.14159265358979323846264338327950288f;
             stack.back() = rt::mat_mul(stack.back(), rt::mat_rotate(rt::mat_identity(), deg * pi / 180.f, x, y, z));
+            xform_id = -1;
         } else if (cmd_is(t, n, "scale")) {
             float x = fl.f(), y = fl.f(), z = fl.f();
             stack.back() = rt::mat_mul(stack.back(), rt::mat_scale(rt::mat_identity(), x, y, z));
+            xform_id = -1;
         } else if (cmd_is(t, n, "output")) {
             const char* o;
             size_t on;

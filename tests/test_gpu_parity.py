@@ -279,7 +279,8 @@ def test_general_grid_resolution(renderer):
     assert (ids != base_ids).mean() < 1e-3
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize("gather", ["f32", "u8"])
+def test_bench_two_ranks_rehearsal(gather):
     """bench.py's multi-rank control flow with two processes sharing the one GPU (collectives over gloo on host
     copies): tiles split, gathered and reassembled frame equals the single-rank frame, ray counts add up."""
     import json
@@ -288,7 +289,7 @@ def test_bench_two_ranks_rehearsal():
     from conftest import ROOT
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "640",
-           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline"]
+           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline", "--gather", gather]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -296,6 +297,27 @@ def test_bench_two_ranks_rehearsal():
     assert out["n_gpus"] == 2 and out["image_check"] is True and out["scaling"] == "strong"
     assert out["config"]["rays_per_frame"]["primary"] == 640 * 360
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("n_pixels", [0, 1, 3, 4, 5, 1023, 160 * 120, 3840 * 2160])
+def test_device_quantise_matches_host_rule(renderer, n_pixels):
+    """(unsigned char)(clamp(c) * 255) on the device, both channel orders, against the host conversion (which the CPU
+    suite pins to the oracle's): values inside, outside and on the edges of [0, 1], negative zero, infinities, NaN."""
+    rng = np.random.default_rng(n_pixels)
+    x = rng.uniform(-0.25, 1.25, (n_pixels, 3)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), 1 / 255, np.nextafter(np.float32(1 / 255), np.float32(0)),
+                        254.999 / 255, np.inf, -np.inf, np.nan, 1e-45, 0.5], np.float32)
+    k = min(x.size, special.size)
+    x.reshape(-1)[:k] = special[:k]
+    want = rt.quantize(x)
+    d_x = torch.from_numpy(x).cuda()
+    for bgr in (False, True):
+        d_q = torch.full((n_pixels + 2, 3), 77, dtype=torch.uint8, device="cuda")     # two guard pixels behind the end
+        renderer.quantize_device(d_x.data_ptr(), n_pixels, d_q.data_ptr(), bgr=bgr)
+        torch.cuda.synchronize()
+        got = d_q.cpu().numpy()
+        assert np.array_equal(got[:n_pixels], want[:, ::-1] if bgr else want)
+        assert (got[n_pixels:] == 77).all()
 
 
 def test_many_lights_and_mixed_primitives(renderer, tmp_path):

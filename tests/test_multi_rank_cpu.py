@@ -23,19 +23,19 @@ def _image(h, w):
     return np.stack([y * 1000 + x, y - x, (y * x) % 7], axis=2).astype(np.float32)
 
 
-def _worker(rank, world, port, h, w, tile_rows, result):
+def _worker(rank, world, port, h, w, tile_rows, dtype, result):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        full = torch.from_numpy(_image(h, w))
-        fg = FrameGather(h, w, 3, tile_rows, rank, world, torch.device("cpu"))
+        full = torch.from_numpy(_image(h, w)).to(dtype)       # 8-bit frames wrap around: still a known image
+        fg = FrameGather(h, w, 3, tile_rows, rank, world, torch.device("cpu"), dtype=dtype)
         rows = rank_rows(h, tile_rows, rank, world)
         for frame in range(2):      # buffers are reused frame after frame
             fg.local_view().copy_(full[torch.as_tensor(rows)] + frame)
             out = fg.gather()
             if rank == 0:
-                assert torch.equal(out, full + frame)
+                assert out.dtype == dtype and torch.equal(out, full + frame)
             else:
                 assert out is None
         if rank == 0:
@@ -44,12 +44,13 @@ def _worker(rank, world, port, h, w, tile_rows, result):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8], ids=["f32", "u8"])
 @pytest.mark.parametrize("world,h,w,tile_rows", [(2, 37, 16, 8), (3, 50, 9, 5), (2, 8, 4, 8)])
-def test_gather_reassembles_the_frame(world, h, w, tile_rows):
+def test_gather_reassembles_the_frame(world, h, w, tile_rows, dtype):
     ctx = mp.get_context("spawn")
     result = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, tile_rows, result)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, tile_rows, dtype, result)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
