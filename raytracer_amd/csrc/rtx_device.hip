@@ -592,11 +592,18 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 }
                 if (path_end) {
                     f3 C = mk(0, 0, 0);
-                    for (int d = top; d >= 0; d--) {
-                        float4 s4;
-                        if (stack_in_lds) s4 = stack_lds[wave][d][lane]; else s4 = stack_g[d];   // one address space per load
+                    const auto fold = [&](const float4 s4) {
                         const float* m = sc.mats + 16 * as_int(s4.w);
                         C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
+                    };
+                    // one loop per address space (the choice is uniform over the launch): a pointer selected inside a
+                    // single loop would turn every read into a flat load
+                    if (stack_in_lds) {
+                        const __attribute__((address_space(3))) float* sl =
+                            (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
+                        for (int d = top; d >= 0; d--) fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
+                    } else {
+                        for (int d = top; d >= 0; d--) fold(stack_g[d]);
                     }
                     f.rgb[3 * pix] = C.x;
                     f.rgb[3 * pix + 1] = C.y;

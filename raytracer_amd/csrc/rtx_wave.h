@@ -67,17 +67,20 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
 // (the reference's 15^3 grid is 106 words), else read from global memory.  Returns the pointer the walkers use.
 #define RT_OCC_LDS_WORDS 128
 struct Occupancy {
-    const unsigned* lds;      // staged copy (LDS), used when global is null
+    // The staged copy is addressed as LDS (address space 3) explicitly: a generic pointer selected between the two
+    // copies would make every test a flat load, which goes through the vector-memory path even when it lands in LDS.
+    unsigned lds_base;        // byte offset of the staged copy in LDS, used when global is null
     const unsigned* global;   // set only when the grid is too large for the LDS copy
     __device__ __forceinline__ bool test(int cell) const {
-        // two separate loads (wave-uniform choice) so that each compiles to its own address space's instruction
-        const unsigned word = global ? global[cell >> 5] : lds[cell >> 5];
+        unsigned word;
+        if (global) word = global[cell >> 5];
+        else word = *(const __attribute__((address_space(3))) unsigned*)(size_t)(lds_base + 4u * (unsigned)(cell >> 5));
         return (word >> (cell & 31)) & 1u;
     }
 };
 __device__ __forceinline__ Occupancy stage_occupancy(const DevGrid& g, unsigned* lds_words) {
     Occupancy o;
-    o.lds = lds_words;
+    o.lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)lds_words;
     o.global = nullptr;
     const int n_words = (g.rx * g.ry * g.rz + 31) >> 5;
     if (g.cocc_bits == nullptr || n_words > RT_OCC_LDS_WORDS) { o.global = g.cocc_bits; return o; }
