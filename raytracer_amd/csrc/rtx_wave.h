@@ -108,7 +108,8 @@ struct Walker {
     int word_base;       // index of the current coarse cell's first occupancy word
     int cur_w;
     uint2 cur;
-    int state;           // 0: about to enter coarse cell (ix,iy,iz); 1: inside its fine block; 2: finished
+    int state;           // 0: about to enter coarse cell (ix,iy,iz); 1: standing on fine cell (lx,ly,lz), not looked
+                         // at yet; 3: done with that fine cell, leaves it at the next step; 2: finished
     bool hit;
 
     // collidesWithBox + start cell + first crossings (src/grid.h:91-138,156-227); same arithmetic as traverse()
@@ -166,8 +167,8 @@ struct Walker {
         state = (stop || !in_grid) ? 2 : 0;
     }
 
-    // Leave the current fine cell.  With an accepted hit in hand (found) the ray finishes as soon as the hit
-    // lies before the next fine cell, or when the walk leaves the block; without one the walk goes on, into
+    // Leave the current fine cell (state 3).  With an accepted hit in hand (found) the ray finishes as soon as the
+    // hit lies before the next fine cell, or when the walk leaves the block; without one the walk goes on, into
     // the next coarse cell when it leaves the block.
     __device__ __forceinline__ void fine_advance(const DevGrid& g, bool found, float best_t) {
         const int k = g.sub;
@@ -184,6 +185,7 @@ struct Walker {
         fny += ay ? fabsf(g.fcell.y * inv_d.y) : 0.0f;
         fnz += az ? fabsf(g.fcell.z * inv_d.z) : 0.0f;
         const bool outside = (unsigned)lx >= (unsigned)k || (unsigned)ly >= (unsigned)k || (unsigned)lz >= (unsigned)k;
+        state = 1;
         if (done) { state = 2; hit = true; }
         else if (beyond || outside) {
             if (found) { state = 2; hit = true; }
@@ -199,6 +201,9 @@ struct Walker {
                                          int& count, bool found, float best_t, WorkCounters& wc) {
         while (state != 2 && budget-- > 0) {
             if (COUNT) wc.w_walk_iters++;
+            // one step = leave the fine cell that is done with, enter a coarse cell if the walk stands before one,
+            // look at the fine cell the walk stands on: the only copy of each piece of the walk in the kernel
+            if (MODE == RT_SEARCH_NESTED && state == 3) fine_advance(g, found, best_t);
             if (state == 0) {
                 if (COUNT) wc.cell_steps++;
                 t_exit = min_of4(nx, ny, nz, t_limit);
@@ -240,7 +245,7 @@ struct Walker {
                     start = b; count = e - b;
                     return true;
                 }
-                fine_advance(g, found, best_t);
+                state = 3;
             }
         }
         return false;
@@ -253,7 +258,7 @@ struct Walker {
             else coarse_advance(g);
         } else {
             if (found && any_hit) { state = 2; hit = true; }
-            else fine_advance(g, found, best_t);
+            else state = 3;                 // the next step leaves the cell, knowing found / best_t
         }
     }
 };
