@@ -925,8 +925,35 @@ __global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_le
         ids[j + 1] = v;
     }
 }
-// Long lists: one workgroup per cell; ids within a cell are distinct, so an element's final position is
-// the number of smaller elements (rank sort through a scratch copy).
+// Medium lists (up to RTX_SORT_LDS_MAX ids): one workgroup per cell, bitonic network over an LDS copy padded to a
+// power of two with INT_MAX.
+#define RTX_SORT_LDS_MAX 16384
+__global__ __launch_bounds__(256) void k_sort_lds(int n_cells, const int* start, int* ids, int min_len) {
+    __shared__ int buf[RTX_SORT_LDS_MAX];
+    const int c = (int)blockIdx.x;
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1], len = e - b;
+    if (len <= min_len || len > RTX_SORT_LDS_MAX) return;      // uniform over the workgroup
+    int padded = 64;
+    while (padded < len) padded <<= 1;
+    for (int i = (int)threadIdx.x; i < padded; i += 256) buf[i] = i < len ? ids[b + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= padded; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = (int)threadIdx.x; t < (padded >> 1); t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const int x = buf[lo], y = buf[hi];
+                if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = (int)threadIdx.x; i < len; i += 256) ids[b + i] = buf[i];
+}
+// Longer lists: ids within a cell are distinct, so an element's final position is the number of smaller elements
+// (rank sort through a scratch copy, quadratic: only for lists that do not fit the LDS sort).
 __global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* start, int* ids, int* scratch, int min_len) {
     const int c = (int)blockIdx.x;
     if (c >= n_cells) return;
@@ -1381,7 +1408,8 @@ static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevB
         hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p, eg,
                            (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
     hipLaunchKernelGGL(k_sort_small, dim3((n_cells + 255) / 256), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
-    hipLaunchKernelGGL(k_sort_large, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, c->scratch_ids.p, 24);
+    hipLaunchKernelGGL(k_sort_lds, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
+    hipLaunchKernelGGL(k_sort_large, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, c->scratch_ids.p, RTX_SORT_LDS_MAX);
     HIP_TRY(hipGetLastError());
     *n_refs = total;
     return RTX_OK;

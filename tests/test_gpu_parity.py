@@ -384,3 +384,32 @@ def test_screen_window_cameras(renderer, tmp_path, cam, w, h):
         rgb, ids, _ = renderer.render(0, 0, 5, rt.SEARCH_NESTED, 8, rank, 3)
         acc[rows], acc_ids[rows] = rgb[rows], ids[rows]
     assert_image_parity(acc, acc_ids, rgb_ref, ids_ref)
+
+
+def test_cell_lists_of_every_length_keep_file_order(renderer, tmp_path):
+    """Cell lists are put into file order by three kernels chosen by list length (up to 24 ids, up to 16384, longer).
+    18 000 small triangles crowd a few cells, a handful of others make short and medium lists; every list must equal
+    the oracle's, and the frame with it."""
+    rng = np.random.default_rng(5)
+    lines = ["size 64 48", "camera 0 0 12 0 0 0 0 1 0 40", "point 5 8 10 1 1 1", "diffuse .6 .5 .4", "specular .2 .2 .2"]
+    centres = np.concatenate([rng.uniform(-0.2, 0.2, (18000, 3)), rng.uniform(-4, 4, (700, 3))]).astype(np.float32)
+    for k, c in enumerate(centres):
+        for d in ((0, 0, 0), (0.05, 0, 0.01), (0, 0.05, 0.01)):
+            lines.append("vertex %.6f %.6f %.6f" % tuple(c + np.array(d)))
+        lines.append(f"tri {3 * k} {3 * k + 1} {3 * k + 2}")
+    path = tmp_path / "crowd.test"
+    path.write_text("\n".join(lines) + "\n")
+    ref = RefScene(str(path))
+    bounds, rstart, rids = ref.grid()
+    lengths = np.diff(rstart)
+    assert lengths.max() > 16384 and ((lengths > 24) & (lengths <= 16384)).any() and ((lengths > 1) & (lengths <= 24)).any()
+    renderer.set_scene(rt.SceneReader().readScene(str(path)))
+    renderer.build_grid(15, 0)
+    start, ids = renderer.download_grid(rt.GRID_REFERENCE)
+    assert np.array_equal(start, rstart) and np.array_equal(ids, rids)
+    fstart, fids = renderer.download_grid(rt.GRID_NESTED)
+    for c in np.flatnonzero(np.diff(fstart) > 1)[:2000]:
+        assert np.all(np.diff(fids[fstart[c]:fstart[c + 1]]) > 0)
+    rgb_ref, ids_ref, _, _ = ref.render(0, 0, 2)
+    rgb, pid, _ = renderer.render(0, 0, 2)
+    assert_image_parity(rgb, pid, rgb_ref, ids_ref)
