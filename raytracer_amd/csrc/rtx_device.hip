@@ -57,7 +57,10 @@ struct DevCamera {
 #define CNT_TRACE_CUR 16
 #define CNT_SHADE_CUR 32
 #define CNT_RESOLVE_CUR 48
-#define CNT_TOTAL 64
+#define CNT_TILES 64        // 8x8 pixel tiles the frame kernel traces (tile list)
+#define CNT_TILES_ALL 65    // set when a fine cell's screen footprint was too large or undefined: every tile is traced
+#define CNT_CLASS 66        // 8 counters: tiles per scheduling class; 74..81: fill cursors per class
+#define CNT_TOTAL 96
 
 struct DevFrame {
     int W, H;                      // full image
@@ -67,10 +70,16 @@ struct DevFrame {
     int bx0;                       // first 8-pixel column block of the traced window
     int lr0;                       // first local row of the traced window (a multiple of 8)
     int n_items0;                  // level-0 work items (8x8 pixel blocks of the traced window * 64)
+    const int* tile_list;          // persistent kernel, optional: the 8x8 blocks to trace, (row block << 16) | column block,
+                                   // their number in counters[CNT_TILES]; null = every block of the window
+    int* tile_cost;                // with tile_list: deepest path level seen per 8x8 block this frame (+2), indexed
+                                   // row block * tbx + column block; feeds the order of the next frame's list
+    int tbx;                       // 8-pixel column blocks per image row
     int max_depth;
     float bias;
     int walk_budget;               // persistent kernel: walk steps a lane may take per round
     int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
+    int drain_num;                 // ... after the cursor is exhausted: that many eighths of the lanes still alive
     DevCamera cam;
     float* rgb;                    // [n_local_rows][W][3]
     int* ids;                      // [n_local_rows][W] or null
@@ -509,18 +518,24 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
 
     // path state of this lane; the ray in flight lives in the walker (w.O, w.D, w.t_limit)
     int pix = -1, level = 0, phase = 0, material = 0;   // phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i
+    int tslot = 0;                                      // 8x8 block of the pixel (index into the cost map)
     f3 rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
     Walker<MODE> w;
     LaneSearch r;
     w.init(g, mk(0, 0, 0), mk(0, 0, 1), FLT_MAX, false);
     r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
     bool exhausted = false;
+    const int n_items = f.tile_list ? 64 * __builtin_amdgcn_readfirstlane(f.counters[CNT_TILES]) : f.n_items0;
 
     for (;;) {
         const bool walking = pix >= 0 && w.state != 2;
         const bool finished = pix >= 0 && w.state == 2;
         const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(pix < 0)));
-        if (!__any(walking) || n_ready >= f.ready_threshold) {
+        // once the cursor is exhausted the wave drains: with few paths left, waiting for a full batch of finished
+        // rays would chain every path to the slowest ray of each generation
+        const int n_alive = __popcll(__ballot(pix >= 0));
+        const int threshold = exhausted ? min(f.ready_threshold, max(1, (n_alive * f.drain_num) >> 3)) : f.ready_threshold;
+        if (!__any(walking) || n_ready >= threshold) {
             if (COUNT) wc.w_updates++;
             const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
             bool begin = false;
@@ -608,6 +623,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     f.rgb[3 * pix] = C.x;
                     f.rgb[3 * pix + 1] = C.y;
                     f.rgb[3 * pix + 2] = C.z;
+                    if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
                     pix = -1;
                 }
             }
@@ -621,10 +637,18 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (idle) {
                     const int i = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
-                    if (i < f.n_items0) {
+                    if (i < n_items) {
                         const int blk = i >> 6, in = i & 63;
-                        const int lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
-                        const int x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
+                        int lr, x;
+                        if (f.tile_list) {
+                            const int t = f.tile_list[blk];
+                            lr = 8 * (t >> 16) + (in >> 3);
+                            x = 8 * (t & 0xffff) + (in & 7);
+                            tslot = (t >> 16) * f.tbx + (t & 0xffff);
+                        } else {
+                            lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
+                            x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
+                        }
                         if (lr < f.n_local_rows && x < f.W) {
                             const int tile = lr / f.tile_rows;
                             const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
@@ -639,7 +663,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                         }
                     }
                 }
-                if (base + n_idle >= f.n_items0) exhausted = true;
+                if (base + n_idle >= n_items) exhausted = true;
             }
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
@@ -649,6 +673,113 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
     if (COUNT) flush_work(wc, f.work);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Screen tiles that can see geometry (nested search, persistent kernel).  A camera ray can only hit a primitive
+// inside an occupied fine cell (every point of a primitive lies in a fine cell that references it), so an 8x8 pixel
+// tile outside the projection of every occupied fine cell returns the miss colour for all its pixels
+// (src/main.cpp:104-106) and is left to the fills.  k_tile_mark projects the eight corners of every occupied fine
+// cell (grown by the binning margin) and marks the tiles of the bounding rectangle grown by two pixels; a cell
+// with a corner beside or behind the eye, or one covering more than 1024 tiles, raises the "every tile" flag
+// instead.  k_tile_list then collects this rank's marked blocks of the traced window.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_tile_mark(DevCamera cam, DevGrid g, DevSparse sp, float pad, int n_fine_cells, int tbx, int tby,
+                            unsigned char* tile_map, int* counters) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_fine_cells) return;
+    const int cell = i / g.cpb, local = i - cell * g.cpb;
+    const int k = g.sub;
+    if (local >= k * k * k) return;                       // padding of the block to whole mask words
+    const uint2 word = sp.words[cell * sp.words_per_block + (local >> 5)];
+    if (!((word.x >> (local & 31)) & 1u)) return;
+    const int cx = cell % g.rx, cy = (cell / g.rx) % g.ry, cz = cell / (g.rx * g.ry);
+    const int lx = local % k, ly = (local / k) % k, lz = local / (k * k);
+    const double lo[3] = {(double)g.lo.x + (double)(cx * k + lx) * g.fcell.x - pad, (double)g.lo.y + (double)(cy * k + ly) * g.fcell.y - pad,
+                          (double)g.lo.z + (double)(cz * k + lz) * g.fcell.z - pad};
+    const double hi[3] = {lo[0] + g.fcell.x + 2.0 * pad, lo[1] + g.fcell.y + 2.0 * pad, lo[2] + g.fcell.z + 2.0 * pad};
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    bool undefined = false;
+    for (int c = 0; c < 8; c++) {
+        const double dx = ((c & 1) ? hi[0] : lo[0]) - cam.eye.x, dy = ((c & 2) ? hi[1] : lo[1]) - cam.eye.y,
+                     dz = ((c & 4) ? hi[2] : lo[2]) - cam.eye.z;
+        const double depth = -(dx * cam.w.x + dy * cam.w.y + dz * cam.w.z);
+        const double extent = fabs(dx) + fabs(dy) + fabs(dz);
+        if (!(depth > 1e-3 * extent) || !(depth > 0)) { undefined = true; break; }
+        const double a = (dx * cam.u.x + dy * cam.u.y + dz * cam.u.z) / depth;
+        const double b = (dx * cam.v.x + dy * cam.v.y + dz * cam.v.z) / depth;
+        const double sx = a / cam.tanx * cam.halfW + cam.halfW - 0.5;      // inverse of Camera::getRayAt (src/geometries.h:339-351)
+        const double sy = cam.halfH - 0.5 - b / cam.tany * cam.halfH;
+        if (!(sx == sx) || !(sy == sy)) { undefined = true; break; }
+        xmin = fmin(xmin, sx); xmax = fmax(xmax, sx);
+        ymin = fmin(ymin, sy); ymax = fmax(ymax, sy);
+    }
+    if (undefined) { counters[CNT_TILES_ALL] = 1; return; }
+    const double margin = 2.0;
+    if (xmax + margin < 0.0 || ymax + margin < 0.0 || xmin - margin > 8.0 * tbx || ymin - margin > 8.0 * tby) return;   // off screen
+    const int tx0 = (int)fmax(0.0, floor((xmin - margin) / 8.0)), tx1 = (int)fmin((double)(tbx - 1), floor((xmax + margin) / 8.0));
+    const int ty0 = (int)fmax(0.0, floor((ymin - margin) / 8.0)), ty1 = (int)fmin((double)(tby - 1), floor((ymax + margin) / 8.0));
+    if (tx1 < tx0 || ty1 < ty0) return;
+    if ((long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) { counters[CNT_TILES_ALL] = 1; return; }
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) tile_map[ty * tbx + tx] = 1;
+}
+
+// One lane per 8x8 block of this rank's traced window (rows are local rows; a block's eight rows may come from
+// different global tiles when the rank split is not in multiples of eight rows).  Blocks that can see geometry are
+// put into eight scheduling classes by the deepest path the block produced in the previous frame of the same
+// geometry (0 = unknown): k_tile_classify counts the classes, k_tile_fill writes the list with the deepest class
+// first, so that the long dependent chains of a frame start early and the frame does not end on them.
+__device__ __forceinline__ bool tile_block(const DevFrame& f, int i, int n_row_blocks, int tbx, const unsigned char* tile_map,
+                                           int& rb, int& bx) {
+    if (i >= n_row_blocks * f.nbx) return false;
+    rb = f.lr0 / 8 + i / f.nbx;
+    bx = f.bx0 + i % f.nbx;
+    bool take = f.counters[CNT_TILES_ALL] != 0;
+    for (int r = 0; r < 8 && !take; r++) {
+        const int lr = 8 * rb + r;
+        if (lr >= f.n_local_rows) break;
+        const int tile = lr / f.tile_rows;
+        const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+        take = tile_map[(y >> 3) * tbx + bx] != 0;
+    }
+    return take;
+}
+__global__ __launch_bounds__(256) void k_tile_classify(DevFrame f, int n_row_blocks, const unsigned char* tile_map, const int* prev_cost,
+                                                       signed char* cls) {
+    __shared__ int cnt[8];
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int rb = 0, bx = 0;
+    const bool take = tile_block(f, i, n_row_blocks, f.tbx, tile_map, rb, bx);
+    int c = -1;
+    if (take) c = prev_cost ? min(max(prev_cost[rb * f.tbx + bx], 0), 7) : 0;
+    if (i < n_row_blocks * f.nbx) cls[i] = (signed char)c;
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+    __syncthreads();
+    if (threadIdx.x < 8 && cnt[threadIdx.x]) {
+        atomicAdd(f.counters + CNT_CLASS + threadIdx.x, cnt[threadIdx.x]);
+        atomicAdd(f.counters + CNT_TILES, cnt[threadIdx.x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_fill(DevFrame f, int n_row_blocks, const signed char* cls, int* tile_list) {
+    __shared__ int cnt[8], base[8], rank[8];
+    if (threadIdx.x < 8) { cnt[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int n = n_row_blocks * f.nbx;
+    const int c = i < n ? (int)cls[i] : -1;
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = (int)threadIdx.x;
+        int offset = 0;                                       // classes above k come first in the list
+        for (int j = k + 1; j < 8; j++) offset += f.counters[CNT_CLASS + j];
+        base[k] = offset + (cnt[k] ? atomicAdd(f.counters + CNT_CLASS + 8 + k, cnt[k]) : 0);
+    }
+    __syncthreads();
+    if (c >= 0) tile_list[base[c] + atomicAdd(&rank[c], 1)] = ((f.lr0 / 8 + i / f.nbx) << 16) | (f.bx0 + i % f.nbx);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1062,6 +1193,14 @@ struct rtx_ctx {
     DevBuf<float4> hP, hN, hD, rO[2], rD[2], hL[RTX_MAX_LEVELS];
     DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
     DevBuf<float4> path_stack;
+    DevBuf<unsigned char> tile_map;
+    DevBuf<signed char> tile_class;
+    DevBuf<int> tile_list, tile_cost[2];
+    int cost_key[6] = {0, 0, 0, 0, 0, 0};   // W, H, tile_rows, rank, world, grid generation the cost map belongs to
+    int cost_cur = 0;             // tile_cost[cost_cur] was written by the last frame
+    bool cost_valid = false;
+    int grid_generation = 0;
+    float fine_pad = 0.0f;        // margin the nested lists were binned with
     DevBuf<float> rgb_local;
     DevBuf<int> ids_local;
     hipEvent_t ev[4 + 3 * 2 * RTX_MAX_LEVELS];
@@ -1450,6 +1589,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
     g.rx = rx; g.ry = ry; g.rz = rz;
 
     c->have_ref = c->have_nested = false;
+    c->grid_generation++;
     if (flags & RTX_GRID_REFERENCE) {
         BinParams bp;
         bp.lo = g.lo; bp.size = g.size; bp.res = g.res;
@@ -1472,6 +1612,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         bp.lo = g.lo; bp.size = g.size; bp.res = mk((float)frx, (float)fry, (float)frz);
         bp.rx = frx; bp.ry = fry; bp.rz = frz;
         bp.pad = 2e-4f * std::max(g.size.x, std::max(g.size.y, g.size.z));
+        c->fine_pad = bp.pad;
         const int wpb = (sub * sub * sub + 31) / 32;
         bp.sub = sub; bp.cpb = 32 * wpb;
         if ((rc = build_lists(c, bp, c->tight_box.p, c->fstart, c->fids, &gi.n_fine_refs))) return rc;
@@ -1611,11 +1752,28 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.bx0 = wx0 / 8;
     f.nbx = wx1 >= wx0 ? wx1 / 8 - f.bx0 + 1 : 0;
     f.n_items0 = f.nbx * ((lr_end - f.lr0 + 7) / 8) * 64;
-    const bool whole_frame = f.lr0 == 0 && lr_end == nl && f.bx0 == 0 && f.nbx == (p->width + 7) / 8;
+    bool whole_frame = f.lr0 == 0 && lr_end == nl && f.bx0 == 0 && f.nbx == (p->width + 7) / 8;
+    // nested search, persistent kernel: only the tiles of the window that can see an occupied fine cell are traced
+    const int tbx = (p->width + 7) / 8, tby = (p->height + 7) / 8;
+    const int n_row_blocks = f.n_items0 > 0 ? (lr_end - f.lr0 + 7) / 8 : 0;
+    bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
+    if (const char* e = getenv("RTX_TILE_CULL")) tile_cull = tile_cull && atoi(e) != 0;          // A/B knob
+    if (tile_cull) {
+        const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
+        if ((rc = c->tile_map.reserve((size_t)tbx * tby)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
+            (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots)) ||
+            (rc = c->tile_cost[1].reserve(n_slots)))
+            return rc;
+        f.tile_list = c->tile_list.p;
+        f.tbx = tbx;
+        whole_frame = false;
+    }
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
     f.walk_budget = 2;
     f.ready_threshold = 32;
+    f.drain_num = 2;
+    if (const char* e = getenv("RTX_DRAIN_NUM")) f.drain_num = std::max(0, atoi(e));
     if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
     if (const char* e = getenv("RTX_READY_THRESHOLD")) f.ready_threshold = std::max(1, atoi(e));
     f.rgb = d_rgb;
@@ -1636,6 +1794,28 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     }
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
     if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 24 * sizeof(unsigned long long), st));
+    if (tile_cull) {
+        HIP_TRY(hipMemsetAsync(c->tile_map.p, 0, (size_t)tbx * tby, st));
+        const int n_fine = (int)c->ginfo.n_fine_cells;
+        hipLaunchKernelGGL(k_tile_mark, dim3((n_fine + 255) / 256), dim3(256), 0, st, f.cam, c->dgrid, c->dsparse, c->fine_pad, n_fine, tbx, tby,
+                           c->tile_map.p, c->counters.p);
+        // the previous frame's per-block path depths order this frame's list if they were recorded for the same
+        // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
+        const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
+        bool feedback = c->cost_valid && memcmp(key, c->cost_key, sizeof key) == 0;
+        if (const char* e = getenv("RTX_TILE_FEEDBACK")) feedback = feedback && atoi(e) != 0;     // A/B knob
+        const int* prev_cost = feedback ? c->tile_cost[c->cost_cur].p : nullptr;
+        c->cost_cur ^= 1;
+        f.tile_cost = c->tile_cost[c->cost_cur].p;
+        memcpy(c->cost_key, key, sizeof key);
+        c->cost_valid = true;
+        HIP_TRY(hipMemsetAsync(f.tile_cost, 0, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), st));
+        const int n_blocks_window = n_row_blocks * f.nbx;
+        hipLaunchKernelGGL(k_tile_classify, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
+                           (const unsigned char*)c->tile_map.p, prev_cost, c->tile_class.p);
+        hipLaunchKernelGGL(k_tile_fill, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
+                           (const signed char*)c->tile_class.p, c->tile_list.p);
+    }
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
         if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels);

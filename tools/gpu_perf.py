@@ -28,6 +28,7 @@ base = None
 
 def run(search, serial, label, lq=True):
     global base
+    r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=search, serial_lanes=serial, level_queues=lq)   # warm
     st = r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, search=search, want_stats=True, count_work=True,
                          serial_lanes=serial, level_queues=lq)
     torch.cuda.synchronize()
