@@ -156,6 +156,16 @@ def main():
         st_t, _ = frame(want_stats=True)
         kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
     kern = np.median(np.array(kern), axis=0)
+    # the same frame without the scheduling hint of the previous frame (what a first frame or a cut to another
+    # camera costs): the library reads the switch at every call
+    os.environ["RTX_TILE_FEEDBACK"] = "0"
+    cold = []
+    for _ in range(5):
+        st_c, _ = frame(want_stats=True)
+        cold.append(st_c.frame_ms)
+    del os.environ["RTX_TILE_FEEDBACK"]
+    frame()
+    cold_ms = float(np.median(cold))
     rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays],
                               dtype=torch.float64, device="cpu" if host_gather else dev)
     if world > 1:
@@ -203,7 +213,9 @@ def main():
                                    f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "
                                    f"{args.gather} gather to rank 0",
                        "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays},
-                       "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1]},
+                       "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1], "frame_without_previous_frame_hint": cold_ms},
+                       "schedule": "screen tiles that can see geometry, ordered by the path depths the previous frame "
+                                   "recorded per tile (order only; every ray of every frame is traced)",
                        "grid": {"refs_reference_lists": gi.n_refs, "fine_cells": gi.n_fine_cells,
                                 "refs_fine": gi.n_fine_refs, "build_ms": gi.build_ms}},
             "roofline": roofline,
