@@ -1100,6 +1100,18 @@ __global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* star
     }
 }
 
+// Per-reference copies of the primitive records in list order (nested grid): frecs[3j..3j+2] = record of fids[j]
+// with the primitive index in the slot that holds the material in the table.
+__global__ void k_expand_records(int n_refs, const int* fids, const float4* prims, float4* frecs) {
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= n_refs) return;
+    const int pid = fids[j];
+    const float4 q2 = prims[3 * pid + 2];
+    frecs[3 * (size_t)j] = prims[3 * pid];
+    frecs[3 * (size_t)j + 1] = prims[3 * pid + 1];
+    frecs[3 * (size_t)j + 2] = make_float4(q2.x, q2.y, as_float(pid), q2.w);
+}
+
 // Sparse view of the nested grid, step 1: occupancy mask of every 32 fine cells and its population count
 __global__ void k_words(int n_words, const int* fstart, unsigned* mask, int* pop) {
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1183,6 +1195,7 @@ struct rtx_ctx {
     DevBuf<unsigned> wmask, cocc_bits;
     DevBuf<int> wpop, wpre, ostart;
     DevBuf<uint2> words;
+    DevBuf<float4> frecs;
     DevGrid dgrid{};
     DevSparse dsparse{};
     // frame workspace
@@ -1641,6 +1654,11 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         g.inv_fcell = mk((float)frx / g.size.x, (float)fry / g.size.y, (float)frz / g.size.z);
         g.fstart = c->fstart.p;
         g.fids = c->fids.p;
+        if ((rc = c->frecs.reserve(3 * (size_t)std::max<int64_t>(gi.n_fine_refs, 1)))) return rc;
+        if (gi.n_fine_refs > 0)
+            hipLaunchKernelGGL(k_expand_records, dim3((unsigned)((gi.n_fine_refs + 255) / 256)), dim3(256), 0, 0, (int)gi.n_fine_refs,
+                               (const int*)c->fids.p, (const float4*)c->prims.p, c->frecs.p);
+        g.frecs = c->frecs.p;
         g.cocc = c->cocc.p;
         gi.sub = sub;
         gi.n_fine_cells = (int64_t)n_blocks * 32 * wpb;

@@ -267,9 +267,12 @@ struct Walker {
 // ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed by its
 // primitive's inverse here (src/geometries.h:179-180).
 template <bool SINGLE_XF, bool COUNT, int PRIMS>
-__device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, int pid,
-                                          WorkCounters& wc) {
-    const float4 q0 = sc.prims[3 * pid], q1 = sc.prims[3 * pid + 1], q2 = sc.prims[3 * pid + 2];
+__device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, const float4* recs,
+                                          int rec, int pid, WorkCounters& wc) {
+    // recs: the primitive table (rec = pid) or the nested grid's per-reference copies in list order, which carry
+    // the primitive index where the table carries the material (pid < 0 on entry)
+    const float4 q0 = recs[3 * rec], q1 = recs[3 * rec + 1], q2 = recs[3 * rec + 2];
+    if (pid < 0) pid = as_int(q2.z);
     if (!SINGLE_XF) {
         const float* m = sc.xinv + 16 * as_int(q2.y);
         const f3 Ow = Oo, Dw = Do;
@@ -381,7 +384,6 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
         }
         l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, w.t_exit);
         l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, as_float(start - excl));
-        const int* ids = MODE == RT_SEARCH_REF ? g.cids : g.fids;
         int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
         for (int base = 0; base < total; base += 64) {
             if (COUNT) wc.w_test_batches++;
@@ -394,8 +396,13 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
             const int p = base + lane;
             if (p < total) {
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
-                const int pid = ids[as_int(rb.w) + p];
-                test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, pid, wc);
+                const int at = as_int(rb.w) + p;             // position in the concatenated cell lists
+                if (MODE == RT_SEARCH_REF) {
+                    const int pid = g.cids[at];
+                    test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, sc.prims, pid, pid, wc);
+                } else {
+                    test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, g.frecs, at, -1, wc);
+                }
             }
         }
     }
