@@ -1733,7 +1733,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const size_t pixels = (size_t)nl * p->width;
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
-    int blocks = c->n_cus * 8;   // 8 workgroups of 4 waves per CU: the work cursors balance the rest
+    int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (const char* e = getenv("RTX_BLOCKS_PER_CU")) blocks = c->n_cus * std::max(1, atoi(e));   // tuning knob
     if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
@@ -1788,8 +1788,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     }
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
-    f.walk_budget = 2;
-    f.ready_threshold = 32;
+    f.walk_budget = 3;
+    f.ready_threshold = 48;
     f.drain_num = 2;
     if (const char* e = getenv("RTX_DRAIN_NUM")) f.drain_num = std::max(0, atoi(e));
     if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
