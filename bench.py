@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--check-image", action="store_true", help="rank 0 also renders the whole frame alone and compares")
+    ap.add_argument("--sync-gather", action="store_true", help="complete every frame's gather before the next frame renders")
     ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
                     help="what travels to rank 0: the float framebuffer (Image3f, the default) or the 8-bit image the "
                          "reference saves, converted on each GPU before the gather (a quarter of the bytes)")
@@ -103,7 +104,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, H, depth = args.width, args.height, args.max_depth
+    W, H, max_depth = args.width, args.height, args.max_depth
     search = rt.SEARCH_NESTED if args.search == "nested" else rt.SEARCH_REFERENCE_LISTS
     sr = rt.SceneReader().readScene(args.scene)
     r = rt.Renderer(local_rank)
@@ -111,23 +112,41 @@ def main():
     gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
 
     as_u8 = args.gather == "u8"
+    # With more than one rank two frames are in flight: the gather of frame k travels while frame k + 1 renders.
+    depth = 2 if world > 1 and not args.sync_gather else 1            # frames in flight
     fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev,
-                     dtype=torch.uint8 if as_u8 else torch.float32)
-    # `local` receives the float rows of this rank; `staged` is what the gather sends (the same tensor unless the
-    # rows are converted to 8 bits first or the collective runs on host copies)
-    staged = torch.empty_like(fg.local_view(), device=dev) if host_gather else fg.local_view()
-    local = torch.empty(tuple(staged.shape), dtype=torch.float32, device=dev) if as_u8 else staged
+                     dtype=torch.uint8 if as_u8 else torch.float32, depth=depth)
+    # per slot: `local` receives the float rows of this rank; `staged` is what the gather sends (the same tensor
+    # unless the rows are converted to 8 bits first or the collective runs on host copies)
+    staged = [torch.empty_like(fg.local_view(b), device=dev) if host_gather else fg.local_view(b) for b in range(depth)]
+    local = [torch.empty(tuple(t.shape), dtype=torch.float32, device=dev) if as_u8 else t for t in staged]
     stream = torch.cuda.current_stream().cuda_stream
 
-    def frame(want_stats=False, count=False, mode=search):
-        st = r.render_device(local.data_ptr(), 0, W, H, depth, mode, args.tile_rows, rank, world, stream=stream,
+    def render(slot=0, want_stats=False, count=False, mode=search):
+        st = r.render_device(local[slot].data_ptr(), 0, W, H, max_depth, mode, args.tile_rows, rank, world, stream=stream,
                              want_stats=want_stats, count_work=count)
         if as_u8:
-            r.quantize_device(local.data_ptr(), local.shape[0] * W, staged.data_ptr(), stream=stream)
+            r.quantize_device(local[slot].data_ptr(), local[slot].shape[0] * W, staged[slot].data_ptr(), stream=stream)
         if host_gather:
-            fg.local_view().copy_(staged)
-        img = fg.gather()
-        return st, img
+            fg.local_view(slot).copy_(staged[slot])
+        return st
+
+    def frame(want_stats=False, count=False, mode=search):
+        """One complete frame: render, exchange, assemble (nothing left in flight)."""
+        st = render(0, want_stats, count, mode)
+        return st, fg.gather(0)
+
+    def frames(n):
+        """n frames back to back; the exchange of a frame is completed when its slot is needed again."""
+        for k in range(n):
+            b = k % depth
+            if fg.in_flight(b):
+                fg.finish(b)
+            render(b)
+            fg.gather_async(b)
+        for b in range(depth):
+            if fg.in_flight(b):
+                fg.finish(b)
 
     def sync():
         torch.cuda.synchronize()
@@ -135,12 +154,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        frame()
+    frames(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame()
+    frames(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -209,9 +226,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
-            "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {depth}, 15^3 grid, search={args.search}, "
+            "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {max_depth}, 15^3 grid, search={args.search}, "
                                    f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "
-                                   f"{args.gather} gather to rank 0",
+                                   f"{args.gather} gather to rank 0, {depth} frame(s) in flight",
                        "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays},
                        "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1], "frame_without_previous_frame_hint": cold_ms},
                        "schedule": "screen tiles that can see geometry, ordered by the path depths the previous frame "
@@ -234,13 +251,13 @@ def main():
             "frac_of_unfused_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_UNFUSED_TFLOPS,
         }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.scene, W, H, depth, args.cpu_row_step // 2, args.cpu_row_step)
+        out["cpu_baseline"] = cpu_baseline(args.scene, W, H, max_depth, args.cpu_row_step // 2, args.cpu_row_step)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if args.check_image:
         _, img = frame()
         if rank == 0:
             whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-            r.render_device(whole.data_ptr(), 0, W, H, depth, search, args.tile_rows, 0, 1, stream=stream)
+            r.render_device(whole.data_ptr(), 0, W, H, max_depth, search, args.tile_rows, 0, 1, stream=stream)
             torch.cuda.synchronize()
             if as_u8:
                 whole_q = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)

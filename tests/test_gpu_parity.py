@@ -284,8 +284,8 @@ def test_general_grid_resolution(renderer):
     assert (ids != base_ids).mean() < 1e-3
 
 
-@pytest.mark.parametrize("gather", ["f32", "u8"])
-def test_bench_two_ranks_rehearsal(gather):
+@pytest.mark.parametrize("gather,extra", [("f32", []), ("u8", []), ("f32", ["--sync-gather"])])
+def test_bench_two_ranks_rehearsal(gather, extra):
     """bench.py's multi-rank control flow with two processes sharing the one GPU (collectives over gloo on host
     copies): tiles split, gathered and reassembled frame equals the single-rank frame, ray counts add up."""
     import json
@@ -293,8 +293,8 @@ def test_bench_two_ranks_rehearsal(gather):
     import sys
     from conftest import ROOT
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--width", "640",
-           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline", "--gather", gather]
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--width", "640",
+           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline", "--gather", gather] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
