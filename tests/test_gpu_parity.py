@@ -441,3 +441,35 @@ def test_schedule_hints_never_change_the_frame(renderer):
                 rgb, ids, _ = renderer.render(W, H, 5, rt.SEARCH_NESTED, tile_rows, rank, world, camera=cams[1])
                 assert np.array_equal(ids[rows], want[1][1][rows])
                 assert np.array_equal(rgb[rows].view(np.int32), want[1][0][rows].view(np.int32))
+
+
+def test_command_line_renderer_writes_the_oracles_image(tmp_path):
+    """`rt scene.test` stands where the reference's main() stands: parse, render, save.  Its PNG and PPM must hold the
+    oracle's frame after the reference's truncating 8-bit conversion; the python `raytrace()` wrapper likewise."""
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "bin", "rt")
+    assert os.path.exists(exe), "build the command-line renderer first (make -C raytracer_amd)"
+    scene = scene_path("scene4-specular")
+    rgb_ref, _, _, _ = RefScene(scene).render(160, 120, 5)
+    want = ref_quantize(rgb_ref)
+    for name in ("cli.png", "cli.ppm"):
+        out = tmp_path / name
+        res = subprocess.run([exe, scene, "--size", "160", "120", "--out", str(out)], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        assert "finished raytracing" in res.stdout and "Written to" in res.stdout
+        got = np.asarray(Image.open(out).convert("RGB"))
+        assert got.shape == want.shape and (np.abs(got.astype(int) - want.astype(int)) > 1).sum() == 0
+        assert (got != want).mean() <= 1e-3
+    res = subprocess.run([exe, str(tmp_path / "missing.test")], capture_output=True, text=True, timeout=60)
+    assert res.returncode != 0 and "cannot open" in res.stderr
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        image, stats = rt.raytrace(scene, 160, 120)     # saves under the scene's `output` name, as the reference does
+    finally:
+        os.chdir(cwd)
+    assert (np.abs(rt.quantize(image.data).astype(int) - want.astype(int)) > 1).sum() == 0 and stats.primary_rays == 160 * 120
+    saved = [f for f in os.listdir(tmp_path) if f not in ("cli.png", "cli.ppm")]
+    assert len(saved) == 1 and (np.asarray(Image.open(tmp_path / saved[0]).convert("RGB")) == rt.quantize(image.data)).all()
