@@ -168,11 +168,13 @@ def main():
 
     # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames)
     st_count, _ = frame(want_stats=True, count=True)
+    # kernel time: HIP events around the frame kernel (on the stream it is launched on), mean over as many frames
+    # as were timed above
     kern = []
-    for _ in range(5):
+    for _ in range(max(args.steps, 5)):
         st_t, _ = frame(want_stats=True)
         kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
-    kern = np.median(np.array(kern), axis=0)
+    kern = np.mean(np.array(kern), axis=0)
     # the same frame without the scheduling hint of the previous frame (what a first frame or a cut to another
     # camera costs): the library reads the switch at every call
     os.environ["RTX_TILE_FEEDBACK"] = "0"
