@@ -75,6 +75,7 @@ struct DevFrame {
     int* tile_cost;                // with tile_list: deepest path level seen per 8x8 block this frame (+2), indexed
                                    // row block * tbx + column block; feeds the order of the next frame's list
     int tbx;                       // 8-pixel column blocks per image row
+    int hint_radius;               // tiles around a tile whose recorded depths count for its class
     int max_depth;
     float bias;
     int walk_budget;               // persistent kernel: walk steps a lane may take per round
@@ -754,7 +755,19 @@ __global__ __launch_bounds__(256) void k_tile_classify(DevFrame f, int n_row_blo
     int rb = 0, bx = 0;
     const bool take = tile_block(f, i, n_row_blocks, f.tbx, tile_map, rb, bx);
     int c = -1;
-    if (take) c = prev_cost ? min(max(prev_cost[rb * f.tbx + bx], 0), 7) : 0;
+    if (take) {
+        c = 0;
+        if (prev_cost) {
+            // the deepest class within `hint_radius` tiles: a camera that moved a little still finds its deep tiles
+            const int nrb = (f.n_local_rows + 7) / 8, R = f.hint_radius;
+            for (int dy = -R; dy <= R; dy++)
+                for (int dx = -R; dx <= R; dx++) {
+                    const int y = rb + dy, x = bx + dx;
+                    if (y >= 0 && y < nrb && x >= 0 && x < f.tbx) c = max(c, prev_cost[y * f.tbx + x]);
+                }
+            c = min(c, 7);
+        }
+    }
     if (i < n_row_blocks * f.nbx) cls[i] = (signed char)c;
     if (c >= 0) atomicAdd(&cnt[c], 1);
     __syncthreads();
@@ -1784,6 +1797,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
             return rc;
         f.tile_list = c->tile_list.p;
         f.tbx = tbx;
+        f.hint_radius = 1;
+        if (const char* e = getenv("RTX_HINT_RADIUS")) f.hint_radius = std::max(0, std::min(16, atoi(e)));
         whole_frame = false;
     }
     f.max_depth = p->max_depth;
