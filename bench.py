@@ -112,41 +112,59 @@ def main():
     gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
 
     as_u8 = args.gather == "u8"
-    # With more than one rank two frames are in flight: the gather of frame k travels while frame k + 1 renders.
-    depth = 2 if world > 1 and not args.sync_gather else 1            # frames in flight
+    # With more than one rank three frames are in flight, each on its own stream and device context.  A rank's share
+    # of a frame is small, its run time is set by the longest chains of dependent rays rather than by the amount of
+    # work; three frames side by side (each kernel launched with a third of the workgroups) fill the GPU, and the
+    # gather of a frame travels while the next ones render.  One rank renders one frame at a time.
+    depth = 3 if world > 1 and not args.sync_gather else 1            # frames in flight
+    wg_per_cu = 0 if depth == 1 else (2 if world == 2 else 1)
+    renderers = [r]
+    for _ in range(1, depth):
+        extra = rt.Renderer(local_rank)
+        extra.set_scene(sr)
+        extra.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+        renderers.append(extra)
+    streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
     fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev,
                      dtype=torch.uint8 if as_u8 else torch.float32, depth=depth)
     # per slot: `local` receives the float rows of this rank; `staged` is what the gather sends (the same tensor
     # unless the rows are converted to 8 bits first or the collective runs on host copies)
     staged = [torch.empty_like(fg.local_view(b), device=dev) if host_gather else fg.local_view(b) for b in range(depth)]
     local = [torch.empty(tuple(t.shape), dtype=torch.float32, device=dev) if as_u8 else t for t in staged]
-    stream = torch.cuda.current_stream().cuda_stream
 
-    def render(slot=0, want_stats=False, count=False, mode=search):
-        st = r.render_device(local[slot].data_ptr(), 0, W, H, max_depth, mode, args.tile_rows, rank, world, stream=stream,
-                             want_stats=want_stats, count_work=count)
+    def render(slot=0, want_stats=False, count=False, mode=search, wg=0):
+        """Enqueues this rank's rows of one frame on the slot's stream (the caller has made it current)."""
+        stream = streams[slot].cuda_stream
+        rr = renderers[slot]
+        st = rr.render_device(local[slot].data_ptr(), 0, W, H, max_depth, mode, args.tile_rows, rank, world, stream=stream,
+                              want_stats=want_stats, count_work=count, workgroups_per_cu=wg)
         if as_u8:
-            r.quantize_device(local[slot].data_ptr(), local[slot].shape[0] * W, staged[slot].data_ptr(), stream=stream)
+            rr.quantize_device(local[slot].data_ptr(), local[slot].shape[0] * W, staged[slot].data_ptr(), stream=stream)
         if host_gather:
             fg.local_view(slot).copy_(staged[slot])
         return st
 
     def frame(want_stats=False, count=False, mode=search):
-        """One complete frame: render, exchange, assemble (nothing left in flight)."""
-        st = render(0, want_stats, count, mode)
-        return st, fg.gather(0)
+        """One complete frame on slot 0: render, exchange, assemble (nothing left in flight)."""
+        with torch.cuda.stream(streams[0]):
+            st = render(0, want_stats, count, mode)
+            img = fg.gather(0)
+        streams[0].synchronize()
+        return st, img
 
     def frames(n):
-        """n frames back to back; the exchange of a frame is completed when its slot is needed again."""
+        """n frames back to back; a slot's exchange is completed when the slot is needed again."""
         for k in range(n):
             b = k % depth
-            if fg.in_flight(b):
-                fg.finish(b)
-            render(b)
-            fg.gather_async(b)
+            with torch.cuda.stream(streams[b]):
+                if fg.in_flight(b):
+                    fg.finish(b)
+                render(b, wg=wg_per_cu)
+                fg.gather_async(b)
         for b in range(depth):
-            if fg.in_flight(b):
-                fg.finish(b)
+            with torch.cuda.stream(streams[b]):
+                if fg.in_flight(b):
+                    fg.finish(b)
 
     def sync():
         torch.cuda.synchronize()
@@ -259,17 +277,18 @@ def main():
         _, img = frame()
         if rank == 0:
             whole = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-            r.render_device(whole.data_ptr(), 0, W, H, max_depth, search, args.tile_rows, 0, 1, stream=stream)
+            r.render_device(whole.data_ptr(), 0, W, H, max_depth, search, args.tile_rows, 0, 1, stream=streams[0].cuda_stream)
             torch.cuda.synchronize()
             if as_u8:
                 whole_q = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-                r.quantize_device(whole.data_ptr(), H * W, whole_q.data_ptr(), stream=stream)
+                r.quantize_device(whole.data_ptr(), H * W, whole_q.data_ptr(), stream=streams[0].cuda_stream)
                 torch.cuda.synchronize()
                 whole = whole_q
             out["image_check"] = bool(torch.equal(img.to(dev), whole))
     if rank == 0:
         print(json.dumps(out))
-    r.close()
+    for rr in renderers:
+        rr.close()
     if world > 1:
         dist.destroy_process_group()
 

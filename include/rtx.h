@@ -158,6 +158,9 @@ typedef struct rtx_render_params {
     int32_t  tile_rows;            /* rows per tile of the multi-GPU split; <= 0 means 8                */
     int32_t  rank, world;          /* this context renders tiles t with t % world == rank; 0,1 = all    */
     uint32_t flags;                /* RTX_RENDER_*                                                      */
+    int32_t  workgroups_per_cu;    /* persistent frame kernel: workgroups launched per compute unit; <= 0 means 4.
+                                      A caller that keeps several frames in flight on their own streams and
+                                      contexts gives each a share (e.g. 1) so that their kernels run side by side */
 } rtx_render_params;
 
 typedef struct rtx_stats {

@@ -49,7 +49,7 @@ class GridInfo(C.Structure):
 class _RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32), ("eps_bias", C.c_float),
                 ("search", C.c_int32), ("tile_rows", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("workgroups_per_cu", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -234,8 +234,8 @@ class SceneReader:
         return c
 
 
-def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags=0):
-    return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags)
+def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags=0, workgroups_per_cu=0):
+    return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu)
 
 
 def local_rows(height, tile_rows=8, rank=0, world=1, width=1):
@@ -313,12 +313,12 @@ class Renderer:
 
     def render_device(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8,
                       rank=0, world=1, stream=None, want_stats=False, count_work=False, camera=None,
-                      eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False):
+                      eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False, workgroups_per_cu=0):
         """Enqueues one frame writing DEVICE memory (raw pointers, e.g. torch tensor data_ptr())."""
         cam = camera if camera is not None else self.scene._camera()
         flags = ((RENDER_COUNT_WORK if count_work else 0) | (RENDER_SERIAL_LANES if serial_lanes else 0) |
                  (RENDER_LEVEL_QUEUES if level_queues else 0))
-        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags)
+        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu)
         st = RenderStats() if want_stats else None
         _check(_load().rtx_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_rgb_ptr),
                                          C.c_void_p(d_ids_ptr) if d_ids_ptr else None,

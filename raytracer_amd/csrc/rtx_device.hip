@@ -1747,6 +1747,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
+    if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
     if (const char* e = getenv("RTX_BLOCKS_PER_CU")) blocks = c->n_cus * std::max(1, atoi(e));   // tuning knob
     if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
