@@ -1,0 +1,166 @@
+// Device-side description of a frame, work cursors, camera rays and the shading terms shared by all kernel families.
+// Part of the device layer of librtx; included by rtx_device.hip only (one translation unit).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// device-side frame description
+// ---------------------------------------------------------------------------------------------------
+struct DevCamera {
+    f3 eye, u, v, w;               // Camera::updateAxes (src/geometries.h:332-337), computed on the host
+    float tanx, tany, halfW, halfH;
+};
+
+// counters[] layout (ints): [0,16) hits per level; [16,32) trace work cursor per level;
+// [32,48) shade work cursor per level; [48,64) resolve work cursor per level
+#define CNT_HITS 0
+#define CNT_TRACE_CUR 16
+#define CNT_SHADE_CUR 32
+#define CNT_RESOLVE_CUR 48
+#define CNT_TILES 64        // 8x8 pixel tiles the frame kernel traces (tile list)
+#define CNT_TILES_ALL 65    // set when a fine cell's screen footprint was too large or undefined: every tile is traced
+#define CNT_CLASS 66        // 8 counters: tiles per scheduling class; 74..81: fill cursors per class
+#define CNT_TOTAL 96
+
+struct DevFrame {
+    int W, H;                      // full image
+    int n_local_rows;              // rows this rank renders
+    int tile_rows, rank, world;
+    int nbx;                       // 8-pixel column blocks per row inside the traced window
+    int bx0;                       // first 8-pixel column block of the traced window
+    int lr0;                       // first local row of the traced window (a multiple of 8)
+    int n_items0;                  // level-0 work items (8x8 pixel blocks of the traced window * 64)
+    const int* tile_list;          // persistent kernel, optional: the 8x8 blocks to trace, (row block << 16) | column block,
+                                   // their number in counters[CNT_TILES]; null = every block of the window
+    int* tile_cost;                // with tile_list: deepest path level seen per 8x8 block this frame (+2), indexed
+                                   // row block * tbx + column block; feeds the order of the next frame's list
+    int tbx;                       // 8-pixel column blocks per image row
+    int hint_radius;               // tiles around a tile whose recorded depths count for its class
+    int max_depth;
+    float bias;
+    int walk_budget;               // persistent kernel: walk steps a lane may take per round
+    int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
+    int drain_num;                 // ... after the cursor is exhausted: that many eighths of the lanes still alive
+    DevCamera cam;
+    float* rgb;                    // [n_local_rows][W][3]
+    int* ids;                      // [n_local_rows][W] or null
+    int* counters;
+    unsigned long long* work;      // instrumented kernels only: 8 x u64 for the trace kernels, then 8 for shade
+    // hit records of the level being processed (reused by every level)
+    float4* hP;                    // position xyz, material index bits
+    float4* hN;                    // normal xyz, primitive index bits
+    float4* hD;                    // incoming ray direction as passed to trace() (not normalised)
+    int* pix0;                     // level 0: local pixel index per hit record
+    // persistent per level; the host fills in the pointers of the level a launch works on
+    float4* hL;                    // this level: L_d xyz (later C_d), material index bits
+    float4* hL_next;               // level d+1 (resolve only)
+    int* hChild;                   // this level: hit record of the mirror ray in level d+1, -1 = none
+    int* hChild_prev;              // level d-1 (trace only)
+    // mirror rays, ping-pong by level parity
+    float4* rO_in;                 // rays of this level (written by level d-1)
+    float4* rD_in;
+    float4* rO_out;                // rays for level d+1
+    float4* rD_out;
+};
+
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
+
+// One 64-ray chunk per call, handed out through an atomic cursor so that waves that drew cheap rays
+// come back for more.  Every wave reaches base >= n eventually because the cursor only grows.
+__device__ __forceinline__ int next_chunk(int* cursor) {
+    int base = 0;
+    if (wave_lane() == 0) base = atomicAdd(cursor, 64);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// Slot allocation for the lanes with `take` set: one atomic per wave.
+__device__ __forceinline__ int wave_alloc(int* counter, bool take) {
+    const unsigned long long mask = __ballot(take);
+    if (mask == 0) return -1;
+    const int lane = wave_lane();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    return take ? base + rank : -1;
+}
+
+__device__ __forceinline__ void flush_work(const WorkCounters& wc, unsigned long long* out) {
+    const unsigned long long v[8] = {wc.tri_tests, wc.sphere_tests, wc.xform_evals, wc.cell_steps,
+                                     wc.fine_steps, wc.light_evals, wc.nearest_hits, wc.rays};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (wave_lane() == 0 && x) atomicAdd(out + k, x);
+    }
+    // wave-level events are incremented by every lane that was active at the time: the maximum over the lanes
+    // is the number of times the wave went through that point
+    const unsigned long long e[4] = {wc.w_rounds, wc.w_walk_iters, wc.w_test_batches, wc.w_updates};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = e[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+        if (wave_lane() == 0 && x) atomicAdd(out + 16 + k, x);
+    }
+    const unsigned long long cy[4] = {wc.c_update, wc.c_walk, wc.c_test, wc.c_fold};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        unsigned long long x = cy[k];
+        for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_down(x, off); x = y > x ? y : x; }
+        if (wave_lane() == 0 && x) atomicAdd(out + 20 + k, x);
+    }
+}
+
+// Camera::getRayAt (src/geometries.h:339-351); tanx, tany, halfW, halfH are per-frame constants
+__device__ __forceinline__ f3 camera_ray(const DevCamera& c, int x, int y) {
+    const float j = (float)x + 0.5f;   // exact in fp32 for any image width below 2^22, as the reference's double add is
+    const float i = (float)y + 0.5f;
+    const float a = c.tanx * ((j - c.halfW) / c.halfW);
+    const float b = c.tany * ((c.halfH - i) / c.halfH);
+    return normalize3(a * c.u + b * c.v - c.w);
+}
+
+// pow(x, y) for the Blinn-Phong term (src/main.cpp:41), x = max(clamp(N.H), 0) in [0, 1] (or NaN), y = shininess.
+// The reference's host libm returns the correctly rounded fp32 power in all but vanishingly rare cases; this
+// evaluates exp2(y * log2(x)) in fp64 (atanh series for the logarithm, Taylor series for the exponential, both to
+// below 1e-16) and rounds once to fp32, which agrees with that except when the exact value lies within ~1e-13
+// relative of a rounding boundary.  Written out by hand because the general library pow needs ~40 more VGPRs.
+__device__ __forceinline__ float pow_shine(float x, float y) {
+    if (y == 0.0f || x == 1.0f) return 1.0f;
+    if (x != x || y != y) return x + y;                        // NaN in, NaN out
+    if (x == 0.0f) return y > 0.0f ? 0.0f : __builtin_inff();
+    if (__builtin_isinf(y)) return y > 0.0f ? 0.0f : __builtin_inff();   // 0 < x < 1 here
+    const long long bits = __double_as_longlong((double)x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), s2 = s * s;        // ln m = 2 atanh(s), |s| <= 0.1716
+    double p = 1.0 / 23.0;
+    p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0); p = fma(p, s2, 1.0);
+    const double log2x = fma(2.0 * s * p, 1.4426950408889634, (double)e);
+    const double z = (double)y * log2x;
+    if (z < -160.0) return 0.0f;
+    if (z > 130.0) return __builtin_inff();
+    const double n = rint(z), t = (z - n) * 0.6931471805599453;   // |t| <= 0.3466
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, t, 1.0 / 479001600.0); q = fma(q, t, 1.0 / 39916800.0); q = fma(q, t, 1.0 / 3628800.0);
+    q = fma(q, t, 1.0 / 362880.0); q = fma(q, t, 1.0 / 40320.0); q = fma(q, t, 1.0 / 5040.0); q = fma(q, t, 1.0 / 720.0);
+    q = fma(q, t, 1.0 / 120.0); q = fma(q, t, 1.0 / 24.0); q = fma(q, t, 1.0 / 6.0); q = fma(q, t, 0.5);
+    q = fma(q, t, 1.0); q = fma(q, t, 1.0);
+    const double scale = __longlong_as_double((long long)((int)n + 1023) << 52);
+    return (float)(q * scale);
+}
+
+// calc_lighting (src/main.cpp:30-45)
+__device__ __forceinline__ f3 light_term(f3 rayDir, f3 L, f3 N, f3 kd, f3 ks, float shininess, f3 lc) {
+    const float lambert = clamp01(dot3(normalize3(L), N));
+    const f3 diff = kd * lc * lambert;
+    const f3 half = normalize3(normalize3(L) + normalize3(-rayDir));
+    const float ph = clamp01(dot3(half, N));
+    const float shine = pow_shine(sel_max(ph, 0.0f), shininess);
+    const f3 spec = ks * lc * shine;
+    return diff + spec;
+}

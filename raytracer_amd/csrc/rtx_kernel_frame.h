@@ -1,0 +1,311 @@
+// Default pipeline: the persistent frame kernel and the kernels that choose and order the screen tiles it traces.
+// Part of the device layer of librtx; included by rtx_device.hip only (one translation unit).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// persistent frame kernel: one launch per frame, every wave keeps a pool of 64 paths alive
+//
+// The level-synchronous kernels above wait at every level for the slowest ray of that level.  Here a wave
+// never waits for another wave: each lane carries one pixel's path through its states (nearest-hit ray of
+// level d -> one shadow ray per light -> mirror ray of level d+1 ...), all 64 lanes share the candidate tests
+// of whatever rays they hold (wave_round), and a lane whose path has ended draws the next pixel from a
+// global cursor.  A path's per-level terms L_d live in a private strip of global memory until the path ends
+// and is folded from its deepest level up (the return path of trace(), src/main.cpp:99-102).
+// Results are bit-identical to the level-synchronous kernels: every ray and every term is computed by the
+// same code, only the schedule differs.
+// ---------------------------------------------------------------------------------------------------
+#define RTX_LDS_LEVELS 6              // paths up to this many levels keep their per-level terms in LDS
+
+template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS>
+__global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
+    __shared__ WaveLds lds[RTX_BLOCK / 64];
+    __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
+    __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+    __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
+    const Occupancy occ = stage_occupancy(g, occ_lds);
+    const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
+    const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
+    WaveLds& l = lds[wave];
+    if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
+    // per-level terms of this lane's path: LDS when the depth allows, else a private strip of global memory
+    const bool stack_in_lds = levels <= RTX_LDS_LEVELS;
+    float4* stack_g = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
+    WorkCounters wc = {};
+
+    // path state of this lane; the ray in flight lives in the walker (w.O, w.D, w.t_limit)
+    int pix = -1, level = 0, phase = 0, material = 0;   // phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i
+    int tslot = 0;                                      // 8x8 block of the pixel (index into the cost map)
+    f3 rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
+    Walker<MODE> w;
+    LaneSearch r;
+    w.init(g, mk(0, 0, 0), mk(0, 0, 1), FLT_MAX, false);
+    r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
+    bool exhausted = false;
+    const int n_items = f.tile_list ? 64 * __builtin_amdgcn_readfirstlane(f.counters[CNT_TILES]) : f.n_items0;
+
+    for (;;) {
+        const bool walking = pix >= 0 && w.state != 2;
+        const bool finished = pix >= 0 && w.state == 2;
+        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(pix < 0)));
+        // once the cursor is exhausted the wave drains: with few paths left, waiting for a full batch of finished
+        // rays would chain every path to the slowest ray of each generation
+        const int n_alive = __popcll(__ballot(pix >= 0));
+        const int threshold = exhausted ? min(f.ready_threshold, max(1, (n_alive * f.drain_num) >> 3)) : f.ready_threshold;
+        if (!__any(walking) || n_ready >= threshold) {
+            if (COUNT) wc.w_updates++;
+            const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
+            bool begin = false;
+            f3 O = w.O, D = w.D;
+            float tl = w.t_limit;
+            if (finished) {
+                bool path_end = false, lit = false;
+                int top = -1, next_light = -1;
+                if (phase == 0) {
+                    if (!w.hit) {                              // src/main.cpp:104-106
+                        path_end = true;
+                        top = level - 1;
+                        if (level == 0 && f.ids) f.ids[pix] = -1;
+                    } else {
+                        if (COUNT) wc.nearest_hits++;
+                        const int prim = r.best_prim;
+                        finish_hit(sc, prim, O, D, r.best_t, P, N, material);
+                        atomicAdd(&hit_count[wave][level], 1);
+                        if (level == 0 && f.ids) f.ids[pix] = prim;
+                        acc = mk(0, 0, 0);
+                        if (sc.n_lights > 0) next_light = 0; else lit = true;
+                    }
+                } else {                                        // src/main.cpp:57-75
+                    const int li = phase - 1;
+                    if (!w.hit) {
+                        const float* lt = sc.lights + 12 * li;
+                        const float* m = sc.mats + 16 * material;
+                        if (COUNT) wc.light_evals++;
+                        const f3 c = light_term(rayDir, D, N, mk(m[3], m[4], m[5]), mk(m[6], m[7], m[8]), m[12], mk(lt[4], lt[5], lt[6]));
+                        if ((int)lt[0] == RTX_LIGHT_POINT) {
+                            const float att = lt[7] + lt[8] * tl + lt[9] * tl * tl;
+                            acc = acc + c / att;
+                        } else {
+                            acc = acc + c;
+                        }
+                    }
+                    if (li + 1 < sc.n_lights) next_light = li + 1; else lit = true;
+                }
+                if (lit) {                                      // src/main.cpp:85-102
+                    const float* m = sc.mats + 16 * material;
+                    const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
+                    const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                    if (stack_in_lds) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
+                    if (level < f.max_depth) {
+                        const f3 V = normalize3(-rayDir);
+                        const f3 R = (2.0f * dot3(V, N) * N) - V;
+                        O = P + f.bias * R;
+                        rayDir = R;
+                        D = normalize3(R);
+                        tl = FLT_MAX;
+                        level++;
+                        phase = 0;
+                        begin = true;
+                    } else {
+                        path_end = true;
+                        top = level;
+                    }
+                }
+                if (next_light >= 0) {
+                    const float* lt = sc.lights + 12 * next_light;
+                    const f3 lpos = mk(lt[1], lt[2], lt[3]);
+                    const bool point = (int)lt[0] == RTX_LIGHT_POINT;
+                    const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
+                    O = P + f.bias * L;
+                    D = L;
+                    tl = point ? dot3(lpos - P, L) : FLT_MAX;
+                    phase = 1 + next_light;
+                    begin = true;
+                }
+                if (path_end) {
+                    f3 C = mk(0, 0, 0);
+                    const auto fold = [&](const float4 s4) {
+                        const float* m = sc.mats + 16 * as_int(s4.w);
+                        C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
+                    };
+                    // one loop per address space (the choice is uniform over the launch): a pointer selected inside a
+                    // single loop would turn every read into a flat load
+                    if (stack_in_lds) {
+                        const __attribute__((address_space(3))) float* sl =
+                            (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
+                        for (int d = top; d >= 0; d--) fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
+                    } else {
+                        for (int d = top; d >= 0; d--) fold(stack_g[d]);
+                    }
+                    f.rgb[3 * pix] = C.x;
+                    f.rgb[3 * pix + 1] = C.y;
+                    f.rgb[3 * pix + 2] = C.z;
+                    if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
+                    pix = -1;
+                }
+            }
+            // lanes without a path draw the next pixels
+            const bool idle = pix < 0;
+            const unsigned long long idle_mask = __ballot(idle);
+            if (!exhausted && idle_mask != 0) {
+                const int n_idle = __popcll(idle_mask);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(f.counters + CNT_TRACE_CUR, n_idle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (idle) {
+                    const int i = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                    if (i < n_items) {
+                        const int blk = i >> 6, in = i & 63;
+                        int lr, x;
+                        if (f.tile_list) {
+                            const int t = f.tile_list[blk];
+                            lr = 8 * (t >> 16) + (in >> 3);
+                            x = 8 * (t & 0xffff) + (in & 7);
+                            tslot = (t >> 16) * f.tbx + (t & 0xffff);
+                        } else {
+                            lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
+                            x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
+                        }
+                        if (lr < f.n_local_rows && x < f.W) {
+                            const int tile = lr / f.tile_rows;
+                            const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+                            pix = lr * f.W + x;
+                            O = f.cam.eye;
+                            rayDir = camera_ray(f.cam, x, y);
+                            D = normalize3(rayDir);             // src/main.cpp:82
+                            tl = FLT_MAX;
+                            level = 0;
+                            phase = 0;
+                            begin = true;
+                        }
+                    }
+                }
+                if (base + n_idle >= n_items) exhausted = true;
+            }
+            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
+            if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
+            if (exhausted && !__any(pix >= 0)) break;
+        }
+        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
+    }
+    if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
+    if (COUNT) flush_work(wc, f.work);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Screen tiles that can see geometry (nested search, persistent kernel).  A camera ray can only hit a primitive
+// inside an occupied fine cell (every point of a primitive lies in a fine cell that references it), so an 8x8 pixel
+// tile outside the projection of every occupied fine cell returns the miss colour for all its pixels
+// (src/main.cpp:104-106) and is left to the fills.  k_tile_mark projects the eight corners of every occupied fine
+// cell (grown by the binning margin) and marks the tiles of the bounding rectangle grown by two pixels; a cell
+// with a corner beside or behind the eye, or one covering more than 1024 tiles, raises the "every tile" flag
+// instead.  k_tile_list then collects this rank's marked blocks of the traced window.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_tile_mark(DevCamera cam, DevGrid g, DevSparse sp, float pad, int n_fine_cells, int tbx, int tby,
+                            unsigned char* tile_map, int* counters) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n_fine_cells) return;
+    const int cell = i / g.cpb, local = i - cell * g.cpb;
+    const int k = g.sub;
+    if (local >= k * k * k) return;                       // padding of the block to whole mask words
+    const uint2 word = sp.words[cell * sp.words_per_block + (local >> 5)];
+    if (!((word.x >> (local & 31)) & 1u)) return;
+    const int cx = cell % g.rx, cy = (cell / g.rx) % g.ry, cz = cell / (g.rx * g.ry);
+    const int lx = local % k, ly = (local / k) % k, lz = local / (k * k);
+    const double lo[3] = {(double)g.lo.x + (double)(cx * k + lx) * g.fcell.x - pad, (double)g.lo.y + (double)(cy * k + ly) * g.fcell.y - pad,
+                          (double)g.lo.z + (double)(cz * k + lz) * g.fcell.z - pad};
+    const double hi[3] = {lo[0] + g.fcell.x + 2.0 * pad, lo[1] + g.fcell.y + 2.0 * pad, lo[2] + g.fcell.z + 2.0 * pad};
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    bool undefined = false;
+    for (int c = 0; c < 8; c++) {
+        const double dx = ((c & 1) ? hi[0] : lo[0]) - cam.eye.x, dy = ((c & 2) ? hi[1] : lo[1]) - cam.eye.y,
+                     dz = ((c & 4) ? hi[2] : lo[2]) - cam.eye.z;
+        const double depth = -(dx * cam.w.x + dy * cam.w.y + dz * cam.w.z);
+        const double extent = fabs(dx) + fabs(dy) + fabs(dz);
+        if (!(depth > 1e-3 * extent) || !(depth > 0)) { undefined = true; break; }
+        const double a = (dx * cam.u.x + dy * cam.u.y + dz * cam.u.z) / depth;
+        const double b = (dx * cam.v.x + dy * cam.v.y + dz * cam.v.z) / depth;
+        const double sx = a / cam.tanx * cam.halfW + cam.halfW - 0.5;      // inverse of Camera::getRayAt (src/geometries.h:339-351)
+        const double sy = cam.halfH - 0.5 - b / cam.tany * cam.halfH;
+        if (!(sx == sx) || !(sy == sy)) { undefined = true; break; }
+        xmin = fmin(xmin, sx); xmax = fmax(xmax, sx);
+        ymin = fmin(ymin, sy); ymax = fmax(ymax, sy);
+    }
+    if (undefined) { counters[CNT_TILES_ALL] = 1; return; }
+    const double margin = 2.0;
+    if (xmax + margin < 0.0 || ymax + margin < 0.0 || xmin - margin > 8.0 * tbx || ymin - margin > 8.0 * tby) return;   // off screen
+    const int tx0 = (int)fmax(0.0, floor((xmin - margin) / 8.0)), tx1 = (int)fmin((double)(tbx - 1), floor((xmax + margin) / 8.0));
+    const int ty0 = (int)fmax(0.0, floor((ymin - margin) / 8.0)), ty1 = (int)fmin((double)(tby - 1), floor((ymax + margin) / 8.0));
+    if (tx1 < tx0 || ty1 < ty0) return;
+    if ((long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) { counters[CNT_TILES_ALL] = 1; return; }
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) tile_map[ty * tbx + tx] = 1;
+}
+
+// One lane per 8x8 block of this rank's traced window (rows are local rows; a block's eight rows may come from
+// different global tiles when the rank split is not in multiples of eight rows).  Blocks that can see geometry are
+// put into eight scheduling classes by the deepest path the block produced in the previous frame of the same
+// geometry (0 = unknown): k_tile_classify counts the classes, k_tile_fill writes the list with the deepest class
+// first, so that the long dependent chains of a frame start early and the frame does not end on them.
+__device__ __forceinline__ bool tile_block(const DevFrame& f, int i, int n_row_blocks, int tbx, const unsigned char* tile_map,
+                                           int& rb, int& bx) {
+    if (i >= n_row_blocks * f.nbx) return false;
+    rb = f.lr0 / 8 + i / f.nbx;
+    bx = f.bx0 + i % f.nbx;
+    bool take = f.counters[CNT_TILES_ALL] != 0;
+    for (int r = 0; r < 8 && !take; r++) {
+        const int lr = 8 * rb + r;
+        if (lr >= f.n_local_rows) break;
+        const int tile = lr / f.tile_rows;
+        const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
+        take = tile_map[(y >> 3) * tbx + bx] != 0;
+    }
+    return take;
+}
+__global__ __launch_bounds__(256) void k_tile_classify(DevFrame f, int n_row_blocks, const unsigned char* tile_map, const int* prev_cost,
+                                                       signed char* cls) {
+    __shared__ int cnt[8];
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int rb = 0, bx = 0;
+    const bool take = tile_block(f, i, n_row_blocks, f.tbx, tile_map, rb, bx);
+    int c = -1;
+    if (take) {
+        c = 0;
+        if (prev_cost) {
+            // the deepest class within `hint_radius` tiles: a camera that moved a little still finds its deep tiles
+            const int nrb = (f.n_local_rows + 7) / 8, R = f.hint_radius;
+            for (int dy = -R; dy <= R; dy++)
+                for (int dx = -R; dx <= R; dx++) {
+                    const int y = rb + dy, x = bx + dx;
+                    if (y >= 0 && y < nrb && x >= 0 && x < f.tbx) c = max(c, prev_cost[y * f.tbx + x]);
+                }
+            c = min(c, 7);
+        }
+    }
+    if (i < n_row_blocks * f.nbx) cls[i] = (signed char)c;
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+    __syncthreads();
+    if (threadIdx.x < 8 && cnt[threadIdx.x]) {
+        atomicAdd(f.counters + CNT_CLASS + threadIdx.x, cnt[threadIdx.x]);
+        atomicAdd(f.counters + CNT_TILES, cnt[threadIdx.x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_fill(DevFrame f, int n_row_blocks, const signed char* cls, int* tile_list) {
+    __shared__ int cnt[8], base[8], rank[8];
+    if (threadIdx.x < 8) { cnt[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int n = n_row_blocks * f.nbx;
+    const int c = i < n ? (int)cls[i] : -1;
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = (int)threadIdx.x;
+        int offset = 0;                                       // classes above k come first in the list
+        for (int j = k + 1; j < 8; j++) offset += f.counters[CNT_CLASS + j];
+        base[k] = offset + (cnt[k] ? atomicAdd(f.counters + CNT_CLASS + 8 + k, cnt[k]) : 0);
+    }
+    __syncthreads();
+    if (c >= 0) tile_list[base[c] + atomicAdd(&rank[c], 1)] = ((f.lr0 / 8 + i / f.nbx) << 16) | (f.bx0 + i % f.nbx);
+}

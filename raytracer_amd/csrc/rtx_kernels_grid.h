@@ -1,0 +1,297 @@
+// Grid build on the device: primitive boxes, scene bounds, count / prefix-scan / scatter of the cell lists, list ordering, sparse view of the nested grid.
+// Part of the device layer of librtx; included by rtx_device.hip only (one translation unit).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// grid build kernels
+// ---------------------------------------------------------------------------------------------------
+// World boxes of every primitive: `ref` as the reference computes them (8 transformed corners, minimum
+// seeded with FLT_MAX and maximum with FLT_MIN -- the smallest positive float, so every maximum is >= ~0;
+// src/geometries.h:122-155,253-259,313-318), `tight` with a true maximum seed.
+__global__ void k_boxes(int n, const float* geom, const int* kind, const int* xform, const float* xfwd, float* ref_box,
+                        float* tight_box) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const float* gp = geom + 9 * i;
+    f3 lo, hi;
+    if (kind[i] == RTX_PRIM_TRIANGLE) {
+        const f3 A = mk(gp[0], gp[1], gp[2]), B = mk(gp[3], gp[4], gp[5]), C = mk(gp[6], gp[7], gp[8]);
+        lo = sel_min(sel_min(A, B), C);
+        hi = sel_max(sel_max(A, B), C);
+    } else {
+        const f3 S = mk(gp[0], gp[1], gp[2]), d = mk(gp[3], gp[3], gp[3]);
+        lo = S - d;
+        hi = S + d;
+    }
+    const float* m = xfwd + 16 * xform[i];
+    f3 rmin = mk(FLT_MAX, FLT_MAX, FLT_MAX), rmax = mk(FLT_MIN, FLT_MIN, FLT_MIN);
+    f3 tmin = rmin, tmax = mk(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int c = 0; c < 8; c++) {
+        const f3 corner = mk((c & 1) ? hi.x : lo.x, (c & 2) ? hi.y : lo.y, (c & 4) ? hi.z : lo.z);
+        const f3 p = mul_point(m, corner);
+        rmin = sel_min(rmin, p);
+        rmax = sel_max(rmax, p);
+        tmin = sel_min(tmin, p);
+        tmax = sel_max(tmax, p);
+    }
+    float* r = ref_box + 6 * i;
+    r[0] = rmin.x; r[1] = rmin.y; r[2] = rmin.z; r[3] = rmax.x; r[4] = rmax.y; r[5] = rmax.z;
+    float* t = tight_box + 6 * i;
+    t[0] = tmin.x; t[1] = tmin.y; t[2] = tmin.z; t[3] = tmax.x; t[4] = tmax.y; t[5] = tmax.z;
+}
+
+// Grid::getSceneBounds (src/grid.h:21-34): min over (start, end), max over (end, start), then -+ 0.001.
+// One workgroup; min/max are exact, so the reduction order does not change the result.
+__global__ __launch_bounds__(1024) void k_scene_bounds(int n, const float* ref_box, float* bounds) {
+    __shared__ float smin[3][1024];
+    __shared__ float smax[3][1024];
+    const int tid = (int)threadIdx.x;
+    f3 mn = mk(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk(FLT_MIN, FLT_MIN, FLT_MIN);
+    for (int i = tid; i < n; i += 1024) {
+        const float* b = ref_box + 6 * i;
+        const f3 s = mk(b[0], b[1], b[2]), e = mk(b[3], b[4], b[5]);
+        mn = sel_min(sel_min(mn, s), e);
+        mx = sel_max(sel_max(mx, e), s);
+    }
+    smin[0][tid] = mn.x; smin[1][tid] = mn.y; smin[2][tid] = mn.z;
+    smax[0][tid] = mx.x; smax[1][tid] = mx.y; smax[2][tid] = mx.z;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+            for (int a = 0; a < 3; a++) {
+                smin[a][tid] = sel_min(smin[a][tid], smin[a][tid + w]);
+                smax[a][tid] = sel_max(smax[a][tid], smax[a][tid + w]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float eps = 0.001f;
+        for (int a = 0; a < 3; a++) {
+            bounds[a] = smin[a][0] - eps;
+            bounds[3 + a] = smax[a][0] + eps;
+        }
+    }
+}
+
+struct BinParams {
+    f3 lo, size, res;              // getCellIndicesAtPosition operands (src/grid.h:53-59)
+    int rx, ry, rz;
+    float pad;                     // box growth (0 for the reference lists)
+    int sub, cpb;                  // sub > 0: block-major numbering, cell = coarse * cpb + local (nested grid)
+};
+
+// Inclusive cell range of one box: clamp(floor((p - lo) * res / size), 0, res - 1) per corner and axis
+__device__ __forceinline__ void cell_range(const BinParams& bp, const float* box, int* c0, int* c1) {
+    const float lo[3] = {bp.lo.x, bp.lo.y, bp.lo.z}, size[3] = {bp.size.x, bp.size.y, bp.size.z};
+    const float res[3] = {bp.res.x, bp.res.y, bp.res.z};
+    for (int a = 0; a < 3; a++) {
+        c0[a] = (int)clampf(floorf(((box[a] - bp.pad) - lo[a]) * res[a] / size[a]), 0.0f, res[a] - 1.0f);
+        c1[a] = (int)clampf(floorf(((box[3 + a] + bp.pad) - lo[a]) * res[a] / size[a]), 0.0f, res[a] - 1.0f);
+    }
+}
+
+// Conservative triangle / box overlap by separating axes (nine edge-cross-axis directions and the triangle's plane;
+// the three box axes are covered by the caller's cell range).  c = box centre, h = half extent already grown by the
+// binning margin, which is orders of magnitude above the rounding of this test, so a triangle that touches the
+// un-grown cell is never rejected.
+__device__ __forceinline__ bool tri_box_overlap(f3 c, f3 h, f3 a, f3 b, f3 cc) {
+    const f3 v0 = a - c, v1 = b - c, v2 = cc - c;
+    const f3 e[3] = {v1 - v0, v2 - v1, v0 - v2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const f3 ed = e[k];
+        // axis (0, -ez, ey)
+        float p0 = ed.y * v0.z - ed.z * v0.y, p1 = ed.y * v1.z - ed.z * v1.y, p2 = ed.y * v2.z - ed.z * v2.y;
+        float rad = fabsf(ed.z) * h.y + fabsf(ed.y) * h.z;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+        // axis (ez, 0, -ex)
+        p0 = ed.z * v0.x - ed.x * v0.z; p1 = ed.z * v1.x - ed.x * v1.z; p2 = ed.z * v2.x - ed.x * v2.z;
+        rad = fabsf(ed.z) * h.x + fabsf(ed.x) * h.z;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+        // axis (-ey, ex, 0)
+        p0 = ed.x * v0.y - ed.y * v0.x; p1 = ed.x * v1.y - ed.y * v1.x; p2 = ed.x * v2.y - ed.y * v2.x;
+        rad = fabsf(ed.y) * h.x + fabsf(ed.x) * h.y;
+        if (fminf(p0, fminf(p1, p2)) > rad || fmaxf(p0, fmaxf(p1, p2)) < -rad) return false;
+    }
+    const f3 nrm = cross3(e[0], e[1]);
+    const float d = dot3(nrm, v0);
+    const float r = h.x * fabsf(nrm.x) + h.y * fabsf(nrm.y) + h.z * fabsf(nrm.z);
+    return fabsf(d) <= r;
+}
+
+// pass 1 (FILL = false): count references per cell; pass 2 (FILL = true): scatter primitive ids,
+// Grid::placeIntoGrid (src/grid.h:76-88) for every primitive at once.  With geom != nullptr (nested grid only) a
+// triangle is referenced only by the cells of its box range that the triangle itself overlaps.
+template <bool FILL>
+__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids,
+                      const float* geom, const int* kind, const int* xform, const float* xfwd) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    int c0[3], c1[3];
+    cell_range(bp, boxes + 6 * i, c0, c1);
+    bool exact = false;
+    f3 wa = mk(0, 0, 0), wb = wa, wc = wa, cellsz = wa, half = wa;
+    if (geom != nullptr && kind[i] == RTX_PRIM_TRIANGLE && (c1[0] > c0[0] || c1[1] > c0[1] || c1[2] > c0[2])) {
+        const float* gp = geom + 9 * i;
+        const float* m = xfwd + 16 * xform[i];
+        wa = mul_point(m, mk(gp[0], gp[1], gp[2]));
+        wb = mul_point(m, mk(gp[3], gp[4], gp[5]));
+        wc = mul_point(m, mk(gp[6], gp[7], gp[8]));
+        cellsz = mk(bp.size.x / bp.res.x, bp.size.y / bp.res.y, bp.size.z / bp.res.z);
+        half = mk(0.5f * cellsz.x + bp.pad, 0.5f * cellsz.y + bp.pad, 0.5f * cellsz.z + bp.pad);
+        exact = true;
+    }
+    for (int z = c0[2]; z <= c1[2]; z++)
+        for (int y = c0[1]; y <= c1[1]; y++)
+            for (int x = c0[0]; x <= c1[0]; x++) {
+                if (exact) {
+                    const f3 centre = mk(bp.lo.x + ((float)x + 0.5f) * cellsz.x, bp.lo.y + ((float)y + 0.5f) * cellsz.y,
+                                         bp.lo.z + ((float)z + 0.5f) * cellsz.z);
+                    if (!tri_box_overlap(centre, half, wa, wb, wc)) continue;
+                }
+                int cell;
+                if (bp.sub > 0) {
+                    const int cx = x / bp.sub, cy = y / bp.sub, cz = z / bp.sub;
+                    const int coarse = cx + (bp.rx / bp.sub) * (cy + (bp.ry / bp.sub) * cz);
+                    cell = coarse * bp.cpb + (x - cx * bp.sub) + bp.sub * ((y - cy * bp.sub) + bp.sub * (z - cz * bp.sub));
+                } else {
+                    cell = x + bp.rx * (y + bp.ry * z);
+                }
+                const int k = atomicAdd(count_or_cursor + cell, 1);
+                if (FILL) ids[start[cell] + k] = i;
+            }
+}
+
+// Exclusive prefix sum over the cell counts, one workgroup walking the array in 1024-wide strips.
+// start has n + 1 entries; start[n] = total.
+__global__ __launch_bounds__(1024) void k_scan(int n, const int* count, int* start) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? count[i] : 0;
+        buf[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = tid >= off ? buf[tid - off] : 0;
+            __syncthreads();
+            buf[tid] += add;
+            __syncthreads();
+        }
+        if (i < n) start[i] = carry + buf[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (tid == 0) start[n] = carry;
+}
+
+// Put every cell's ids in ascending (= file) order.  Short lists: one lane per cell, insertion sort.
+__global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_len) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1];
+    if (e - b < 2 || e - b > max_len) return;
+    for (int i = b + 1; i < e; i++) {
+        const int v = ids[i];
+        int j = i - 1;
+        while (j >= b && ids[j] > v) { ids[j + 1] = ids[j]; j--; }
+        ids[j + 1] = v;
+    }
+}
+// Medium lists (up to RTX_SORT_LDS_MAX ids): one workgroup per cell, bitonic network over an LDS copy padded to a
+// power of two with INT_MAX.
+#define RTX_SORT_LDS_MAX 16384
+__global__ __launch_bounds__(256) void k_sort_lds(int n_cells, const int* start, int* ids, int min_len) {
+    __shared__ int buf[RTX_SORT_LDS_MAX];
+    const int c = (int)blockIdx.x;
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1], len = e - b;
+    if (len <= min_len || len > RTX_SORT_LDS_MAX) return;      // uniform over the workgroup
+    int padded = 64;
+    while (padded < len) padded <<= 1;
+    for (int i = (int)threadIdx.x; i < padded; i += 256) buf[i] = i < len ? ids[b + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= padded; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = (int)threadIdx.x; t < (padded >> 1); t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j clear
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const int x = buf[lo], y = buf[hi];
+                if ((x > y) == up) { buf[lo] = y; buf[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = (int)threadIdx.x; i < len; i += 256) ids[b + i] = buf[i];
+}
+// Longer lists: ids within a cell are distinct, so an element's final position is the number of smaller elements
+// (rank sort through a scratch copy, quadratic: only for lists that do not fit the LDS sort).
+__global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* start, int* ids, int* scratch, int min_len) {
+    const int c = (int)blockIdx.x;
+    if (c >= n_cells) return;
+    const int b = start[c], e = start[c + 1], len = e - b;
+    if (len <= min_len) return;
+    for (int i = (int)threadIdx.x; i < len; i += 256) scratch[b + i] = ids[b + i];
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < len; i += 256) {
+        const int v = scratch[b + i];
+        int rank = 0;
+        for (int j = 0; j < len; j++) rank += scratch[b + j] < v ? 1 : 0;
+        ids[b + rank] = v;
+    }
+}
+
+// Per-reference copies of the primitive records in list order (nested grid): frecs[3j..3j+2] = record of fids[j]
+// with the primitive index in the slot that holds the material in the table.
+__global__ void k_expand_records(int n_refs, const int* fids, const float4* prims, float4* frecs) {
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= n_refs) return;
+    const int pid = fids[j];
+    const float4 q2 = prims[3 * pid + 2];
+    frecs[3 * (size_t)j] = prims[3 * pid];
+    frecs[3 * (size_t)j + 1] = prims[3 * pid + 1];
+    frecs[3 * (size_t)j + 2] = make_float4(q2.x, q2.y, as_float(pid), q2.w);
+}
+
+// Sparse view of the nested grid, step 1: occupancy mask of every 32 fine cells and its population count
+__global__ void k_words(int n_words, const int* fstart, unsigned* mask, int* pop) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= n_words) return;
+    unsigned m = 0;
+    for (int b = 0; b < 32; b++) m |= (fstart[32 * w + b + 1] > fstart[32 * w + b]) ? (1u << b) : 0u;
+    mask[w] = m;
+    pop[w] = __popc(m);
+}
+// step 2 (after the prefix sum of pop): (mask, occupied cells before the word) pairs and the compact CSR starts
+__global__ void k_compact(int n_words, const int* fstart, const unsigned* mask, const int* wpre, uint2* words, int* ostart) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= n_words) return;
+    const unsigned m = mask[w];
+    int o = wpre[w];
+    words[w] = make_uint2(m, (unsigned)o);
+    for (int b = 0; b < 32; b++)
+        if (m & (1u << b)) ostart[o++] = fstart[32 * w + b];
+    if (w == n_words - 1) ostart[wpre[n_words]] = fstart[32 * n_words];
+}
+// coarse-cell occupancy of the nested grid: any fine cell of the block holds a primitive
+__global__ void k_occupancy(int n_blocks, int words_per_block, const unsigned* mask, unsigned char* occ) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_blocks) return;
+    unsigned any = 0;
+    for (int w = 0; w < words_per_block; w++) any |= mask[c * words_per_block + w];
+    occ[c] = any ? 1 : 0;
+}
+// ... and the same packed 32 coarse cells per word
+__global__ void k_occupancy_bits(int n_blocks, const unsigned char* occ, unsigned* bits) {
+    const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= (n_blocks + 31) / 32) return;
+    unsigned m = 0;
+    for (int b = 0; b < 32 && 32 * w + b < n_blocks; b++) m |= occ[32 * w + b] ? (1u << b) : 0u;
+    bits[w] = m;
+}
