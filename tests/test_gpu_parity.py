@@ -473,3 +473,67 @@ def test_command_line_renderer_writes_the_oracles_image(tmp_path):
     assert (np.abs(rt.quantize(image.data).astype(int) - want.astype(int)) > 1).sum() == 0 and stats.primary_rays == 160 * 120
     saved = [f for f in os.listdir(tmp_path) if f not in ("cli.png", "cli.ppm")]
     assert len(saved) == 1 and (np.asarray(Image.open(tmp_path / saved[0]).convert("RGB")) == rt.quantize(image.data)).all()
+
+
+def _random_scene(rng, n_tris, n_spheres, n_lights):
+    """A random scene in the reference's file format: triangles and spheres under nested random transforms, mirror
+    and matte materials, point and directional lights with attenuation, axis-aligned and oblique cameras."""
+    w, h = int(rng.integers(33, 97)), int(rng.integers(25, 73))
+    eye = rng.uniform(-1, 1, 3) * [2, 2, 0] + [0, 0, rng.uniform(6, 14)]
+    if rng.random() < 0.3:
+        eye = np.array([0.0, 0.0, 10.0])                    # looks straight down -z: rays with zero components
+    lines = [f"size {w} {h}", "camera %g %g %g 0 0 0 0 1 0 %g" % (*eye, rng.uniform(25, 70)), "maxverts 100000"]
+    for _ in range(n_lights):
+        if rng.random() < 0.5:
+            lines.append("attenuation %g %g %g" % tuple(rng.choice([[1, 0, 0], [1, 0.1, 0.05], [0.5, 0.2, 0]])))
+            lines.append("point %g %g %g %g %g %g" % (*rng.uniform(-6, 6, 3), *rng.uniform(0.2, 0.9, 3)))
+        else:
+            lines.append("directional %g %g %g %g %g %g" % (*rng.normal(size=3), *rng.uniform(0.1, 0.6, 3)))
+    n_vert = 0
+    depth = 0
+    for k in range(n_tris + n_spheres):
+        if rng.random() < 0.25 and depth < 3:
+            lines.append("pushTransform"); depth += 1
+            lines.append("translate %g %g %g" % tuple(rng.uniform(-2.5, 2.5, 3)))
+            if rng.random() < 0.6:
+                lines.append("rotate %g %g %g %g" % (*rng.normal(size=3), rng.uniform(-180, 180)))
+            if rng.random() < 0.6:
+                lines.append("scale %g %g %g" % tuple(rng.uniform(0.4, 1.8, 3)))
+        elif rng.random() < 0.2 and depth > 0:
+            lines.append("popTransform"); depth -= 1
+        if rng.random() < 0.5:
+            lines.append("ambient %g %g %g" % tuple(rng.uniform(0, 0.2, 3)))
+            lines.append("diffuse %g %g %g" % tuple(rng.uniform(0, 0.8, 3)))
+            lines.append("specular %g %g %g" % tuple(rng.choice([0.0, 0.3, 0.9]) * np.ones(3)))
+            lines.append("shininess %g" % rng.choice([1, 5, 20, 100]))
+            lines.append("emission %g %g %g" % tuple(rng.choice([0.0, 0.05]) * np.ones(3)))
+        if k < n_tris:
+            c = rng.uniform(-3, 3, 3)
+            size = rng.choice([0.05, 0.5, 2.5])
+            for _ in range(3):
+                lines.append("vertex %g %g %g" % tuple(c + rng.uniform(-size, size, 3)))
+            lines.append(f"tri {n_vert} {n_vert + 1} {n_vert + 2}")
+            if rng.random() < 0.05:
+                lines.append(f"tri {n_vert} {n_vert} {n_vert + 1}")         # zero-area triangle
+            n_vert += 3
+        else:
+            lines.append("sphere %g %g %g %g" % (*rng.uniform(-3, 3, 3), rng.choice([0.1, 0.6, 1.5])))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenes_match_the_oracle(renderer, tmp_path, seed):
+    rng = np.random.default_rng(1000 + seed)
+    text = _random_scene(rng, int(rng.integers(0, 120)), int(rng.integers(0, 30)), int(rng.integers(0, 4)))
+    path = tmp_path / "random.test"
+    path.write_text(text)
+    depth = int(rng.integers(0, 7))
+    rgb_ref, ids_ref, _, cnt = RefScene(str(path), counting=True).render(0, 0, depth)
+    renderer.set_scene(rt.SceneReader().readScene(str(path)))
+    renderer.build_grid(15, int(rng.choice([0, 1, 2, 5])))
+    for mode in MODES:
+        for kw in PIPELINES.values():
+            for _ in range(2):                       # the second frame runs with the first one's scheduling hint
+                rgb, ids, st = renderer.render(0, 0, depth, mode, **kw)
+                assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+                assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
