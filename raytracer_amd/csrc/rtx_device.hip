@@ -93,7 +93,7 @@ struct rtx_ctx {
     DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp;
     DevBuf<unsigned char> cocc;
     DevBuf<unsigned> wmask, cocc_bits;
-    DevBuf<int> wpop, wpre, ostart;
+    DevBuf<int> wpop, wpre, ostart, ocell;
     DevBuf<uint2> words;
     DevBuf<float4> frecs;
     DevGrid dgrid{};
@@ -537,9 +537,9 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_words, (const int*)c->wpop.p, c->wpre.p);
         int n_occ = 0;
         HIP_TRY(hipMemcpy(&n_occ, c->wpre.p + n_words, sizeof(int), hipMemcpyDeviceToHost));
-        if ((rc = c->ostart.reserve((size_t)n_occ + 1))) return rc;
+        if ((rc = c->ostart.reserve((size_t)n_occ + 1)) || (rc = c->ocell.reserve((size_t)std::max(n_occ, 1)))) return rc;
         hipLaunchKernelGGL(k_compact, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, (const unsigned*)c->wmask.p,
-                           (const int*)c->wpre.p, c->words.p, c->ostart.p);
+                           (const int*)c->wpre.p, c->words.p, c->ostart.p, c->ocell.p);
         hipLaunchKernelGGL(k_occupancy, dim3((n_blocks + 255) / 256), dim3(256), 0, 0, n_blocks, wpb, (const unsigned*)c->wmask.p, c->cocc.p);
         if ((rc = c->cocc_bits.reserve((size_t)(n_blocks + 31) / 32))) return rc;
         hipLaunchKernelGGL(k_occupancy_bits, dim3(((n_blocks + 31) / 32 + 255) / 256), dim3(256), 0, 0, n_blocks, (const unsigned char*)c->cocc.p, c->cocc_bits.p);
@@ -679,9 +679,10 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     if (const char* e = getenv("RTX_TILE_CULL")) tile_cull = tile_cull && atoi(e) != 0;          // A/B knob
     if (tile_cull) {
         const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
-        if ((rc = c->tile_map.reserve((size_t)tbx * tby)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
-            (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots)) ||
-            (rc = c->tile_cost[1].reserve(n_slots)))
+        // + 16 bytes: the clear kernel writes whole 16-byte words
+        if ((rc = c->tile_map.reserve((size_t)tbx * tby + 16)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
+            (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots + 4)) ||
+            (rc = c->tile_cost[1].reserve(n_slots + 4)))
             return rc;
         f.tile_list = c->tile_list.p;
         f.tbx = tbx;
@@ -709,28 +710,50 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
 
     hipEvent_t* ev = c->ev;
     HIP_TRY(hipEventRecord(ev[0], st));              // frame time includes the fills
-    if (!whole_frame) {
-        HIP_TRY(hipMemsetAsync(d_rgb, 0, pixels * 3 * sizeof(float), st));            // 0.0f
-        if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xff, pixels * sizeof(int32_t), st));   // -1
+    // one launch clears everything a frame starts from; caller buffers whose size or address is not a multiple of 16
+    // bytes fall back to memsets
+    {
+        ClearRanges cr;
+        memset(&cr, 0, sizeof cr);
+        auto add = [&](void* ptr, size_t bytes, unsigned pattern) {
+            cr.ptr[cr.n] = (uint4*)ptr; cr.words[cr.n] = (long long)((bytes + 15) / 16); cr.pattern[cr.n] = pattern; cr.n++;
+        };
+        if (!whole_frame) {
+            const size_t rgb_bytes = pixels * 3 * sizeof(float), id_bytes = pixels * sizeof(int32_t);
+            if (((uintptr_t)d_rgb & 15u) == 0 && rgb_bytes % 16 == 0) add(d_rgb, rgb_bytes, 0u);            // 0.0f
+            else HIP_TRY(hipMemsetAsync(d_rgb, 0, rgb_bytes, st));
+            if (d_ids) {
+                if (((uintptr_t)d_ids & 15u) == 0 && id_bytes % 16 == 0) add(d_ids, id_bytes, 0xffffffffu);   // -1
+                else HIP_TRY(hipMemsetAsync(d_ids, 0xff, id_bytes, st));
+            }
+        }
+        add(c->counters.p, CNT_TOTAL * sizeof(int), 0u);
+        if (count) add(c->work.p, 24 * sizeof(unsigned long long), 0u);
+        if (tile_cull) {
+            // the map this frame records its per-block path depths into (the other one orders this frame's list)
+            c->cost_cur ^= 1;
+            add(c->tile_map.p, (size_t)tbx * tby, 0u);
+            add(c->tile_cost[c->cost_cur].p, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), 0u);
+        }
+        long long total = 0;
+        for (int k = 0; k < cr.n; k++) total += cr.words[k];
+        const int clear_blocks = (int)std::min<long long>((total + 255) / 256, (long long)c->n_cus * 16);
+        hipLaunchKernelGGL(k_frame_clear, dim3(std::max(clear_blocks, 1)), dim3(256), 0, st, cr);
     }
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, CNT_TOTAL * sizeof(int), st));
-    if (count) HIP_TRY(hipMemsetAsync(c->work.p, 0, 24 * sizeof(unsigned long long), st));
     if (tile_cull) {
-        HIP_TRY(hipMemsetAsync(c->tile_map.p, 0, (size_t)tbx * tby, st));
-        const int n_fine = (int)c->ginfo.n_fine_cells;
-        hipLaunchKernelGGL(k_tile_mark, dim3((n_fine + 255) / 256), dim3(256), 0, st, f.cam, c->dgrid, c->dsparse, c->fine_pad, n_fine, tbx, tby,
-                           c->tile_map.p, c->counters.p);
+        const int n_occ = (int)c->ginfo.n_occupied_fine_cells;
+        if (n_occ > 0)
+            hipLaunchKernelGGL(k_tile_mark, dim3((n_occ + 255) / 256), dim3(256), 0, st, f.cam, c->dgrid, (const int*)c->ocell.p, c->fine_pad,
+                               n_occ, tbx, tby, c->tile_map.p, c->counters.p);
         // the previous frame's per-block path depths order this frame's list if they were recorded for the same
         // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
         const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
         bool feedback = c->cost_valid && memcmp(key, c->cost_key, sizeof key) == 0;
         if (const char* e = getenv("RTX_TILE_FEEDBACK")) feedback = feedback && atoi(e) != 0;     // A/B knob
-        const int* prev_cost = feedback ? c->tile_cost[c->cost_cur].p : nullptr;
-        c->cost_cur ^= 1;
+        const int* prev_cost = feedback ? c->tile_cost[c->cost_cur ^ 1].p : nullptr;
         f.tile_cost = c->tile_cost[c->cost_cur].p;
         memcpy(c->cost_key, key, sizeof key);
         c->cost_valid = true;
-        HIP_TRY(hipMemsetAsync(f.tile_cost, 0, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), st));
         const int n_blocks_window = n_row_blocks * f.nbx;
         hipLaunchKernelGGL(k_tile_classify, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
                            (const unsigned char*)c->tile_map.p, prev_cost, c->tile_class.p);

@@ -200,15 +200,13 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
 // with a corner beside or behind the eye, or one covering more than 1024 tiles, raises the "every tile" flag
 // instead.  k_tile_list then collects this rank's marked blocks of the traced window.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_tile_mark(DevCamera cam, DevGrid g, DevSparse sp, float pad, int n_fine_cells, int tbx, int tby,
+__global__ void k_tile_mark(DevCamera cam, DevGrid g, const int* occupied_cells, float pad, int n_occupied, int tbx, int tby,
                             unsigned char* tile_map, int* counters) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n_fine_cells) return;
+    const int o = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (o >= n_occupied) return;
+    const int i = occupied_cells[o];                      // fine cell number: block * cells per block + local
     const int cell = i / g.cpb, local = i - cell * g.cpb;
     const int k = g.sub;
-    if (local >= k * k * k) return;                       // padding of the block to whole mask words
-    const uint2 word = sp.words[cell * sp.words_per_block + (local >> 5)];
-    if (!((word.x >> (local & 31)) & 1u)) return;
     const int cx = cell % g.rx, cy = (cell / g.rx) % g.ry, cz = cell / (g.rx * g.ry);
     const int lx = local % k, ly = (local / k) % k, lz = local / (k * k);
     const double lo[3] = {(double)g.lo.x + (double)(cx * k + lx) * g.fcell.x - pad, (double)g.lo.y + (double)(cy * k + ly) * g.fcell.y - pad,

@@ -269,14 +269,15 @@ __global__ void k_words(int n_words, const int* fstart, unsigned* mask, int* pop
     pop[w] = __popc(m);
 }
 // step 2 (after the prefix sum of pop): (mask, occupied cells before the word) pairs and the compact CSR starts
-__global__ void k_compact(int n_words, const int* fstart, const unsigned* mask, const int* wpre, uint2* words, int* ostart) {
+// and, per occupied cell, its fine cell number (block * cells per block + local)
+__global__ void k_compact(int n_words, const int* fstart, const unsigned* mask, const int* wpre, uint2* words, int* ostart, int* ocell) {
     const int w = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (w >= n_words) return;
     const unsigned m = mask[w];
     int o = wpre[w];
     words[w] = make_uint2(m, (unsigned)o);
     for (int b = 0; b < 32; b++)
-        if (m & (1u << b)) ostart[o++] = fstart[32 * w + b];
+        if (m & (1u << b)) { ocell[o] = 32 * w + b; ostart[o++] = fstart[32 * w + b]; }
     if (w == n_words - 1) ostart[wpre[n_words]] = fstart[32 * n_words];
 }
 // coarse-cell occupancy of the nested grid: any fine cell of the block holds a primitive

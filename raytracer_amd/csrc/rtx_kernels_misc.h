@@ -3,6 +3,26 @@
 #pragma once
 
 // ---------------------------------------------------------------------------------------------------
+// Start of a frame in one launch: the miss colour (0) over the colour buffer, -1 over the id map, zeros over the
+// counters and the tile maps.  Up to six (pointer, 16-byte words, 32-bit pattern) ranges, each a multiple of 16
+// bytes long and 16-byte aligned (device allocations are; the host rounds the lengths up inside the allocations).
+// ---------------------------------------------------------------------------------------------------
+struct ClearRanges {
+    uint4* ptr[6];
+    long long words[6];
+    unsigned pattern[6];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_frame_clear(ClearRanges r) {
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    for (int k = 0; k < r.n; k++) {
+        const uint4 v = make_uint4(r.pattern[k], r.pattern[k], r.pattern[k], r.pattern[k]);
+        uint4* p = r.ptr[k];
+        for (long long i = tid; i < r.words[k]; i += stride) p[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 8-bit conversion of a float framebuffer on the device: (unsigned char)(clamp(c) * 255), truncating, as
 // Image3f::write3fPpm and get_3b_bgr_buffer do (src/Image3f.h:63-80,154-170).  Four pixels per lane: three
 // 16-byte loads, one 12-byte store.  Pure streaming, 15 bytes of traffic per pixel.
