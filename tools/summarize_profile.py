@@ -13,21 +13,24 @@ os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
-lines = [f"PMC summary ({tag}): k_frame on scene7 @ 3840x2160 depth 5, nested search sub 6, per launch (mean of 3 launches).",
+lines = [f"PMC summary ({tag}): k_frame on scene7 @ 3840x2160 depth 5, nested search sub 6, per launch (mean over the launches after the first).",
          "Collected with rocprofv3 --pmc, one pass per line group (tools/profile_round.sh)."]
 vals = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
-        agg, n, dur = collections.defaultdict(float), collections.Counter(), []
+        per, dur = collections.defaultdict(list), {}
         for r in csv.DictReader(open(f)):
-            if "k_frame" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]] += float(r["Counter_Value"])
-                n[r["Counter_Name"]] += 1
-                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            if "k_frame<" in r["Kernel_Name"]:
+                per[r["Counter_Name"]].append((int(r["Start_Timestamp"]), float(r["Counter_Value"])))
+                dur[int(r["Start_Timestamp"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        # the first launch runs without the previous frame's scheduling hint: leave it out
+        starts = sorted(dur)[1:] if len(dur) > 1 else sorted(dur)
+        agg = {k: sum(val for t, val in rows if t in set(starts)) / max(1, sum(1 for t, _ in rows if t in set(starts))) for k, rows in per.items()}
         for k in agg:
-            vals[k] = agg[k] / n[k]
-        lines.append(f"[{os.path.basename(d)}] kernel duration under this pass: {sum(dur) / max(len(dur), 1) / 1e6:.3f} ms")
-        lines += [f"    {k:32s} {agg[k] / n[k]:.6g}" for k in sorted(agg)]
+            vals[k] = agg[k]
+        lines.append(f"[{os.path.basename(d)}] kernel duration under this pass: {sum(dur[t] for t in starts) / max(len(starts), 1) / 1e6:.3f} ms "
+                     f"({len(starts)} launches)")
+        lines += [f"    {k:32s} {agg[k]:.6g}" for k in sorted(agg)]
 v = vals
 lines.append("derived:")
 if "SQ_THREAD_CYCLES_VALU" in v:
