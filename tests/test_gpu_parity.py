@@ -537,3 +537,34 @@ def test_random_scenes_match_the_oracle(renderer, tmp_path, seed):
                 rgb, ids, st = renderer.render(0, 0, depth, mode, **kw)
                 assert_image_parity(rgb, ids, rgb_ref, ids_ref)
                 assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
+def test_bench_line_has_the_contracted_fields():
+    """One-GPU bench.py on a reduced frame: exactly one JSON line with every field the benchmark contract names."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--width", "640", "--height", "360",
+           "--cpu-row-step", "48"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(out[key], kind), key
+    assert out["vs_baseline"] is None and out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 1
+    assert out["higher_is_better"] is True and out["dtype"] == "f32" and "workload" in out["config"]
+    rays = out["config"]["rays_per_frame"]
+    assert rays["primary"] == 640 * 360 and rays["total"] == rays["primary"] + rays["shadow"] + rays["reflection"]
+    assert abs(out["value"] - rays["total"] / (out["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * out["value"]
+    roof = out["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == out["unit"] and "rows" in cpu["sample"]
+    assert out["gpu_over_cpu"] > 100
