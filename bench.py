@@ -237,7 +237,8 @@ def main():
         # not run the profiler
         import glob
         traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        if traffic_files and world == 1 and args.search == "nested":
+        default_workload = (W, H, max_depth, args.sub) == (3840, 2160, 5, 6) and os.path.basename(args.scene) == "scene7.test"
+        if traffic_files and world == 1 and args.search == "nested" and default_workload:
             with open(traffic_files[-1]) as fh:
                 roofline["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
             roofline["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
