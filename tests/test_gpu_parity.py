@@ -568,3 +568,20 @@ def test_bench_line_has_the_contracted_fields():
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == out["unit"] and "rows" in cpu["sample"]
     assert out["gpu_over_cpu"] > 100
+
+
+@pytest.mark.parametrize("name,which", [("scene1", 1), ("scene1", 2), ("scene1", 3), ("scene1", 4), ("scene2", 1), ("scene2", 2),
+                                        ("scene2", 3), ("scene3", 1)])
+def test_course_scenes_all_cameras(renderer, tmp_path, name, which):
+    """The three course scenes under every camera their files list (res/scene1.test:9-12, res/scene2.test:17-19): the
+    frames the reference's own JPEG fixtures show, GPU against oracle."""
+    from test_oracle_fixtures import _with_camera
+    path = _with_camera(tmp_path, name, which)
+    rgb_ref, ids_ref, _, cnt = RefScene(path, counting=True).render(0, 0, 5)
+    renderer.set_scene(rt.SceneReader().readScene(path))
+    renderer.build_grid(15, 0)
+    for mode in MODES:
+        for kw in PIPELINES.values():
+            rgb, ids, st = renderer.render(0, 0, 5, mode, **kw)
+            assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
