@@ -9,9 +9,10 @@
 //
 // PARITY UNPINNED at the bit level: the reference cannot be built in this image
 // (glm and OpenCV are absent) and it ships no tests or golden vectors; the only
-// fixtures it holds are lossy course JPEGs (res/scene1-camera4.jpg,
-// res/scene2-camera1.jpg, res/scene3.jpg), against which this oracle is pinned
-// coarsely (silhouette / mean-error checks in tests/test_oracle_fixtures.py).
+// fixtures it holds are eight lossy course JPEGs (res/scene1-camera1..4.jpg,
+// res/scene2-camera1..3.jpg, res/scene3.jpg), against which this oracle is
+// pinned coarsely, each under the camera its scene file lists for it
+// (silhouette / mean-error checks in tests/test_oracle_fixtures.py).
 //
 // Each function cites the reference lines it follows (paths relative to
 // /root/reference).
