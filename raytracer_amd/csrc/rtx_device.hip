@@ -516,9 +516,28 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
     }
     if (flags & RTX_GRID_NESTED) {
         if (sub == 0) {
-            // aim at a few primitives per occupied fine cell: total fine cells ~ 8 x primitive count
-            const double target = std::cbrt(8.0 * std::max(n, 1) / ((double)rx * ry * rz));
-            sub = (int)std::min(32.0, std::max(1.0, std::ceil(target)));
+            // Aim at about one primitive per occupied fine cell: count the references the tight boxes make at the
+            // coarse resolution, take the mean per occupied coarse cell and split each axis by its cube root.
+            // (A count by primitives alone misjudges scenes of few large primitives, whose cells are crowded by
+            // the same walls over and over.)
+            BinParams cp;
+            cp.lo = g.lo; cp.size = g.size; cp.res = g.res;
+            cp.rx = rx; cp.ry = ry; cp.rz = rz;
+            cp.pad = 0.0f;
+            cp.sub = 0; cp.cpb = 0;
+            const int n_coarse = rx * ry * rz;
+            if ((rc = c->cell_tmp.reserve((size_t)n_coarse + 1))) return rc;
+            HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_coarse + 1) * sizeof(int), 0));
+            if (n > 0)
+                hipLaunchKernelGGL((k_bin<false>), dim3((n + 255) / 256), dim3(256), 0, 0, n, cp, (const float*)c->tight_box.p, c->cell_tmp.p,
+                                   (const int*)nullptr, (int*)nullptr, (const float*)nullptr, (const int*)c->kind.p, (const int*)c->xform.p,
+                                   (const float*)c->xfwd.p);
+            std::vector<int> counts((size_t)n_coarse);
+            HIP_TRY(hipMemcpy(counts.data(), c->cell_tmp.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost));
+            long long refs = 0, occupied = 0;
+            for (int v : counts) { refs += v; occupied += v > 0; }
+            const double per_cell = occupied > 0 ? (double)refs / (double)occupied : 1.0;
+            sub = (int)std::min(32.0, std::max(1.0, std::floor(std::cbrt(per_cell) + 0.5)));
         }
         const int frx = rx * sub, fry = ry * sub, frz = rz * sub;
         BinParams bp;
