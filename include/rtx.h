@@ -112,7 +112,8 @@ int  rtx_set_scene(rtx_ctx* ctx, const rtx_scene_view* view);
  *                       needed by RTX_SEARCH_REFERENCE_LISTS.
  *   RTX_GRID_NESTED     additionally a fine grid of (rx*sub, ry*sub, rz*sub) cells nested in the coarse
  *                       cells, binned by tight boxes; needed by RTX_SEARCH_NESTED.  sub in [1, 64];
- *                       sub = 0 lets the library choose from the primitive count.
+ *                       sub = 0 lets the library choose (cube root of the mean number of tight-box
+ *                       references per occupied coarse cell).
  * The reference always uses rx = ry = rz = 15 (src/grid.h:37). */
 #define RTX_GRID_REFERENCE 1u
 #define RTX_GRID_NESTED    2u
