@@ -585,3 +585,35 @@ def test_course_scenes_all_cameras(renderer, tmp_path, name, which):
             rgb, ids, st = renderer.render(0, 0, 5, mode, **kw)
             assert_image_parity(rgb, ids, rgb_ref, ids_ref)
             assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
+def test_frames_in_flight_on_their_own_streams_and_contexts():
+    """Three contexts, three streams, frames of different cameras enqueued round-robin without waiting in between,
+    each kernel launched with a share of the workgroups: every frame equals the one rendered alone."""
+    sr = rt.SceneReader().readScene(scene_path("scene7"))
+    W, H = 512, 288
+    cams = [sr._camera() for _ in range(3)]
+    cams[1].eye[0] = 7.0
+    cams[2].fov_deg = 20.0
+    slots = []
+    for _ in range(3):
+        r = rt.Renderer(0)
+        r.set_scene(sr)
+        r.build_grid(15, 4)
+        slots.append((r, torch.cuda.Stream(), torch.empty((H, W, 3), dtype=torch.float32, device="cuda"),
+                      torch.empty((H, W), dtype=torch.int32, device="cuda")))
+    want = [slots[0][0].render(W, H, 5, camera=c) for c in cams]
+    try:
+        for wg in (1, 2, 0, 64):
+            for k in range(9):
+                r, s, d_rgb, d_ids = slots[k % 3]
+                r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, camera=cams[(k // 3) % 3], stream=s.cuda_stream,
+                                workgroups_per_cu=wg)
+                if k % 3 == 2:                     # three frames are in flight: check them, then go on
+                    torch.cuda.synchronize()
+                    for r2, s2, rgb2, ids2 in slots:
+                        assert np.array_equal(rgb2.cpu().numpy().view(np.int32), want[(k // 3) % 3][0].view(np.int32))
+                        assert np.array_equal(ids2.cpu().numpy(), want[(k // 3) % 3][1])
+    finally:
+        for r, _, _, _ in slots:
+            r.close()
