@@ -207,7 +207,9 @@ struct Walker {
             if (state == 0) {
                 if (COUNT) wc.cell_steps++;
                 t_exit = min_of4(nx, ny, nz, t_limit);
-                const int cell = ix + g.rx * iy + g.rx * g.ry * iz;
+                // 24-bit multiplies (full rate; the 32-bit ones take four times as long): indices stay below 2^10 per
+                // axis and below 2^22 per coarse cell number, see the limits in rtx_build_grid
+                const int cell = ix + __mul24(g.rx, iy) + __mul24(g.rx * g.ry, iz);
                 if (MODE == RT_SEARCH_REF) {
                     const int b = g.cstart[cell], e = g.cstart[cell + 1];
                     if (e > b) { start = b; count = e - b; return true; }
@@ -215,18 +217,19 @@ struct Walker {
                 } else if (occ.test(cell)) {
                     const int k = g.sub;
                     const f3 p = O + fmaxf(t_in, 0.0f) * D;
-                    const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - ix * k, 0), k - 1);
-                    const int fy = min(max((int)floorf((p.y - g.lo.y) * g.inv_fcell.y) - iy * k, 0), k - 1);
-                    const int fz = min(max((int)floorf((p.z - g.lo.z) * g.inv_fcell.z) - iz * k, 0), k - 1);
+                    const int bx = __mul24(ix, k), by = __mul24(iy, k), bz = __mul24(iz, k);
+                    const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - bx, 0), k - 1);
+                    const int fy = min(max((int)floorf((p.y - g.lo.y) * g.inv_fcell.y) - by, 0), k - 1);
+                    const int fz = min(max((int)floorf((p.z - g.lo.z) * g.inv_fcell.z) - bz, 0), k - 1);
                     lx = fx; ly = fy; lz = fz;
                     const float inf = __builtin_inff();
-                    const float px = g.lo.x + (float)(ix * k + fx + (D.x > 0 ? 1 : 0)) * g.fcell.x;
-                    const float py = g.lo.y + (float)(iy * k + fy + (D.y > 0 ? 1 : 0)) * g.fcell.y;
-                    const float pz = g.lo.z + (float)(iz * k + fz + (D.z > 0 ? 1 : 0)) * g.fcell.z;
+                    const float px = g.lo.x + (float)(bx + fx + (D.x > 0 ? 1 : 0)) * g.fcell.x;
+                    const float py = g.lo.y + (float)(by + fy + (D.y > 0 ? 1 : 0)) * g.fcell.y;
+                    const float pz = g.lo.z + (float)(bz + fz + (D.z > 0 ? 1 : 0)) * g.fcell.z;
                     fnx = D.x != 0 ? (px - O.x) * inv_d.x : inf;
                     fny = D.y != 0 ? (py - O.y) * inv_d.y : inf;
                     fnz = D.z != 0 ? (pz - O.z) * inv_d.z : inf;
-                    word_base = cell * sp.words_per_block;
+                    word_base = __mul24(cell, sp.words_per_block);
                     state = 1;
                 } else {
                     coarse_advance(g);
@@ -235,7 +238,7 @@ struct Walker {
             if (MODE == RT_SEARCH_NESTED && state == 1) {
                 if (COUNT) wc.fine_steps++;
                 const int k = g.sub;
-                const int local = lx + k * (ly + k * lz);
+                const int local = lx + __mul24(k, ly + __mul24(k, lz));
                 const int w = word_base + (local >> 5);
                 if (w != cur_w) { cur = sp.words[w]; cur_w = w; }
                 const unsigned bit = 1u << (local & 31);
