@@ -74,21 +74,30 @@ __device__ __forceinline__ bool quotient_negative(float num, float den) {
 // Triangle::intersect (src/geometries.h:305-311): Cramer solve of [e1 e2 D](beta,gamma,t)^T = A - O,
 // hit iff beta >= 0 && gamma >= 0 && beta + gamma <= 1 && t > 0.  The three IEEE divides are skipped when
 // a numerator's sign already decides a failing comparison (the common case); the accepted set is unchanged.
-__device__ __forceinline__ bool hit_triangle(f3 A, f3 e1, f3 e2, f3 O, f3 D, float& t_out) {
+// Split in two so that the wave-cooperative search can run the divisions of several batches together:
+// numerators + sign tests, then quotients + comparisons.  hit_triangle is the two in sequence.
+__device__ __forceinline__ bool triangle_numerators(f3 A, f3 e1, f3 e2, f3 O, f3 D, float& nb, float& ng, float& nt, float& detA) {
     const f3 d = A - O;
-    const float detA = det3(e1, e2, D);
-    const float nb = det3(d, e2, D);
-    const float ng = det3(e1, d, D);
-    const float nt = det3(e1, e2, d);
+    detA = det3(e1, e2, D);
+    nb = det3(d, e2, D);
+    ng = det3(e1, d, D);
+    nt = det3(e1, e2, d);
     // t > 0 fails for every quotient that is negative, zero (either sign) or NaN
     if (((as_int(nt) ^ as_int(detA)) < 0) || nt == 0.0f) return false;
     if (quotient_negative(nb, detA) || quotient_negative(ng, detA)) return false;
+    return true;
+}
+__device__ __forceinline__ bool triangle_quotients(float nb, float ng, float nt, float detA, float& t_out) {
     const float beta = nb / detA, gamma = ng / detA, t = nt / detA;
     if (beta >= 0 && gamma >= 0 && beta + gamma <= 1 && t > 0) {
         t_out = t;
         return true;
     }
     return false;
+}
+__device__ __forceinline__ bool hit_triangle(f3 A, f3 e1, f3 e2, f3 O, f3 D, float& t_out) {
+    float nb, ng, nt, detA;
+    return triangle_numerators(A, e1, e2, O, D, nb, ng, nt, detA) && triangle_quotients(nb, ng, nt, detA, t_out);
 }
 
 // Sphere::intersect (src/geometries.h:221-251) followed by the sanitising HitInfo constructor (:72-77)

@@ -34,7 +34,11 @@ struct __attribute__((aligned(16))) WaveLds {
     float4 ray_b[64];              // ray direction xyz, w = bits of (list start - exclusive prefix)
     unsigned long long best[64];   // (t bits << 32) | primitive, all ones = none
     int owner_at[64];              // per pair slot of the current 64-pair batch: lane whose list starts there, else 0
+    // triangle candidates that passed the sign tests and await their divisions (ring of RT_CAND_RING entries)
+    float4 cand_n[128];            // numerators of beta, gamma, t and the common denominator
+    int2 cand_who[128];            // owner lane, primitive index
 };
+#define RT_CAND_RING 128
 
 #define RT_BEST_NONE 0xffffffffffffffffull
 
@@ -269,9 +273,10 @@ struct Walker {
 // One test of pair (owner ray, primitive).  SINGLE_XF: the scene has exactly one transform and the LDS holds the
 // ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed by its
 // primitive's inverse here (src/geometries.h:179-180).
+// Returns true for a triangle whose divisions are still to be done (numerators in cand, index in cand_pid).
 template <bool SINGLE_XF, bool COUNT, int PRIMS>
-__device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, const float4* recs,
-                                          int rec, int pid, WorkCounters& wc) {
+__device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, const float4* recs,
+                                          int rec, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
     // recs: the primitive table (rec = pid) or the nested grid's per-reference copies in list order, which carry
     // the primitive index where the table carries the material (pid < 0 on entry)
     const float4 q0 = recs[3 * rec], q1 = recs[3 * rec + 1], q2 = recs[3 * rec + 2];
@@ -283,20 +288,35 @@ __device__ __forceinline__ void test_pair(const DevScene& sc, WaveLds& l, int ow
         Do = mul_dir(m, Dw);
         if (COUNT) wc.xform_evals++;
     }
-    float t;
-    bool ok;
     // PRIMS: 1 = the scene holds only triangles, 2 = only spheres (the other test is compiled out), 0 = both
     if (PRIMS == 1 || (PRIMS == 0 && as_int(q2.w) == RT_KIND_TRI)) {
         if (COUNT) wc.tri_tests++;
-        ok = hit_triangle(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), Oo, Do, t);
-    } else {
-        if (COUNT) wc.sphere_tests++;
-        ok = hit_sphere(mk(q0.x, q0.y, q0.z), q0.w, Oo, Do, t);
+        // a triangle that survives the sign tests is handed back: its divisions run later, many at a time
+        cand_pid = pid;
+        return triangle_numerators(mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), mk(q1.z, q1.w, q2.x), Oo, Do, cand.x, cand.y, cand.z, cand.w);
     }
-    if (ok && t < bound) {
+    if (COUNT) wc.sphere_tests++;
+    float t;
+    if (hit_sphere(mk(q0.x, q0.y, q0.z), q0.w, Oo, Do, t) && t < bound) {
         // t > 0 here, so its bit pattern orders like its value; the low word breaks ties toward the lower index
         const unsigned long long key = ((unsigned long long)(unsigned)as_int(t) << 32) | (unsigned)pid;
         atomicMin(&l.best[owner], key);
+    }
+    return false;
+}
+
+// Divisions and acceptance of `n` queued triangle candidates starting at ring position `head` (n <= 64)
+__device__ __forceinline__ void finish_candidates(WaveLds& l, int head, int n) {
+    const int lane = lane_id();
+    if (lane < n) {
+        const int at = (head + lane) & (RT_CAND_RING - 1);
+        const float4 c = l.cand_n[at];
+        const int2 who = l.cand_who[at];
+        float t;
+        if (triangle_quotients(c.x, c.y, c.z, c.w, t) && t < l.ray_a[who.x].w) {
+            const unsigned long long key = ((unsigned long long)(unsigned)as_int(t) << 32) | (unsigned)who.y;
+            atomicMin(&l.best[who.x], key);
+        }
     }
 }
 
@@ -388,6 +408,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
         l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, w.t_exit);
         l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, as_float(start - excl));
         int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
+        int q_head = 0, q_tail = 0;                  // ring positions of the queued triangle candidates (wave-uniform)
         for (int base = 0; base < total; base += 64) {
             if (COUNT) wc.w_test_batches++;
             l.owner_at[lane] = 0;
@@ -397,16 +418,41 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
             const int owner = max(wave_inclusive_max(l.owner_at[lane]), carry);
             carry = __builtin_amdgcn_readlane(owner, 63);
             const int p = base + lane;
+            bool queued = false;
+            float4 cand = make_float4(0, 0, 0, 0);
+            int cand_pid = -1;
             if (p < total) {
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
                 const int at = as_int(rb.w) + p;             // position in the concatenated cell lists
                 if (MODE == RT_SEARCH_REF) {
                     const int pid = g.cids[at];
-                    test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, sc.prims, pid, pid, wc);
+                    queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, sc.prims, pid, pid,
+                                                                cand, cand_pid, wc);
                 } else {
-                    test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, g.frecs, at, -1, wc);
+                    queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, g.frecs, at, -1,
+                                                                cand, cand_pid, wc);
                 }
             }
+            // The divisions are the dearest part of a triangle test and one pair in five gets that far: the
+            // survivors are queued and divided 64 at a time instead of a few per batch.
+            const unsigned long long qm = __ballot(queued);
+            if (qm != 0) {
+                if (queued) {
+                    const int at = (q_tail + __popcll(qm & ((1ull << lane) - 1ull))) & (RT_CAND_RING - 1);
+                    l.cand_n[at] = cand;
+                    l.cand_who[at] = make_int2(owner, cand_pid);
+                }
+                q_tail += __popcll(qm);
+                if (q_tail - q_head >= 64) {
+                    wave_lds_sync();
+                    finish_candidates(l, q_head, 64);
+                    q_head += 64;
+                }
+            }
+        }
+        if (q_tail > q_head) {                       // at most 63 left
+            wave_lds_sync();
+            finish_candidates(l, q_head, q_tail - q_head);
         }
     }
     wave_lds_sync();                                 // the atomic minima of all lanes land before the owners read them
