@@ -714,6 +714,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.walk_budget = 3;
     f.ready_threshold = 48;
     f.drain_num = 2;
+    f.helpers = 1;
+    if (const char* e = getenv("RTX_HELPERS")) f.helpers = atoi(e) != 0;
     if (const char* e = getenv("RTX_DRAIN_NUM")) f.drain_num = std::max(0, atoi(e));
     if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
     if (const char* e = getenv("RTX_READY_THRESHOLD")) f.ready_threshold = std::max(1, atoi(e));

@@ -40,6 +40,7 @@ struct DevFrame {
     int walk_budget;               // persistent kernel: walk steps a lane may take per round
     int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
     int drain_num;                 // ... after the cursor is exhausted: that many eighths of the lanes still alive
+    int helpers;                   // persistent kernel: idle lanes of a draining wave trace the shadow rays of fresh hits
     DevCamera cam;
     float* rgb;                    // [n_local_rows][W][3]
     int* ids;                      // [n_local_rows][W] or null

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+    __shared__ int outstanding[RTX_BLOCK / 64][64];   // per path lane: helpers that have not reported yet
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
@@ -33,7 +34,11 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     WorkCounters wc = {};
 
     // path state of this lane; the ray in flight lives in the walker (w.O, w.D, w.t_limit)
-    int pix = -1, level = 0, phase = 0, material = 0;   // phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i
+    //   pix >= 0   the lane carries the path of that pixel        pix == -1   the lane is idle
+    //   pix <= -2  the lane traces the shadow rays of one hit for the path on lane -2 - pix (see "helpers" below)
+    //   phase 0: nearest-hit ray in flight; 1 + i: shadow ray of light i; -1 / -2: the path has ended at level /
+    //   level - 1 and waits for its helpers before it folds
+    int pix = -1, level = 0, phase = 0, material = 0;
     int tslot = 0;                                      // 8x8 block of the pixel (index into the cost map)
     f3 rayDir = mk(0, 0, 1), P = mk(0, 0, 0), N = mk(0, 0, 1), acc = mk(0, 0, 0);
     Walker<MODE> w;
@@ -42,14 +47,24 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
     bool exhausted = false;
     const int n_items = f.tile_list ? 64 * __builtin_amdgcn_readfirstlane(f.counters[CNT_TILES]) : f.n_items0;
+    // Helpers.  The shadow rays of a hit and the mirror ray that leaves it do not depend on each other, but one lane
+    // traces them one after the other.  Once the wave can draw no new pixels its idle lanes take over the shadow
+    // rays of fresh hits (hit record handed over through LDS), the path's own lane goes on with the mirror ray at
+    // once, and the chain of dependent rays of a depth-5 path shrinks from 12 to 7.  The helper writes the level's
+    // term into the path's slot; a path folds only when all its helpers have reported (pending_helpers).
+    const bool helpers = f.helpers != 0 && stack_in_lds;
+    outstanding[wave][lane] = 0;
+    int guard = 0;                                      // bounds the loop whatever happens: a frame needs a few thousand rounds
 
     for (;;) {
-        const bool walking = pix >= 0 && w.state != 2;
-        const bool finished = pix >= 0 && w.state == 2;
-        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(pix < 0)));
+        const bool alive = pix != -1;
+        const bool walking = alive && w.state != 2;
+        const bool finished = alive && w.state == 2 && phase >= 0;
+        const bool waiting = alive && w.state == 2 && phase < 0;
+        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(!alive)));
         // once the cursor is exhausted the wave drains: with few paths left, waiting for a full batch of finished
         // rays would chain every path to the slowest ray of each generation
-        const int n_alive = __popcll(__ballot(pix >= 0));
+        const int n_alive = __popcll(__ballot(alive));
         const int threshold = exhausted ? min(f.ready_threshold, max(1, (n_alive * f.drain_num) >> 3)) : f.ready_threshold;
         if (!__any(walking) || n_ready >= threshold) {
             if (COUNT) wc.w_updates++;
@@ -57,9 +72,15 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
             bool begin = false;
             f3 O = w.O, D = w.D;
             float tl = w.t_limit;
+            const bool worker = pix <= -2;
+            bool path_end = false, lit = false, want_helper = false, has_helper = false, act = finished;
+            int top = -1, next_light = -1;
+            if (waiting && atomicAdd(&outstanding[wave][lane], 0) == 0) {       // every helper has reported
+                path_end = true;
+                top = phase == -1 ? level : level - 1;
+                act = true;
+            }
             if (finished) {
-                bool path_end = false, lit = false;
-                int top = -1, next_light = -1;
                 if (phase == 0) {
                     if (!w.hit) {                              // src/main.cpp:104-106
                         path_end = true;
@@ -72,7 +93,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                         atomicAdd(&hit_count[wave][level], 1);
                         if (level == 0 && f.ids) f.ids[pix] = prim;
                         acc = mk(0, 0, 0);
-                        if (sc.n_lights > 0) next_light = 0; else lit = true;
+                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && exhausted; } else lit = true;
                     }
                 } else {                                        // src/main.cpp:57-75
                     const int li = phase - 1;
@@ -90,11 +111,52 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     }
                     if (li + 1 < sc.n_lights) next_light = li + 1; else lit = true;
                 }
-                if (lit) {                                      // src/main.cpp:85-102
+            }
+            // hand fresh hits to idle lanes: the k-th lane with a fresh hit is served by the k-th idle lane
+            if (helpers && exhausted) {
+                const unsigned long long req_mask = __ballot(want_helper), idle_mask = __ballot(!alive);
+                const int n_match = min(__popcll(req_mask), __popcll(idle_mask));
+                if (n_match > 0) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const int req_rank = __popcll(req_mask & below), idle_rank = __popcll(idle_mask & below);
+                    if (want_helper && req_rank < n_match) {
+                        l.ray_a[req_rank] = make_float4(P.x, P.y, P.z, as_float(material));
+                        l.ray_b[req_rank] = make_float4(N.x, N.y, N.z, as_float(level));
+                        l.cand_n[req_rank] = make_float4(rayDir.x, rayDir.y, rayDir.z, as_float(lane));
+                        atomicAdd(&outstanding[wave][lane], 1);
+                        has_helper = true;
+                        next_light = -1;
+                    }
+                    wave_lds_sync();
+                    if (!alive && idle_rank < n_match) {
+                        const float4 a = l.ray_a[idle_rank], b = l.ray_b[idle_rank], c = l.cand_n[idle_rank];
+                        P = mk(a.x, a.y, a.z); material = as_int(a.w);
+                        N = mk(b.x, b.y, b.z); level = as_int(b.w);
+                        rayDir = mk(c.x, c.y, c.z);
+                        pix = -2 - as_int(c.w);
+                        acc = mk(0, 0, 0);
+                        next_light = 0;
+                        act = true;
+                    }
+                    wave_lds_sync();
+                }
+            }
+            if (act) {
+                if (lit && worker) {                            // a helper reports: the level's term goes into the path's slot
                     const float* m = sc.mats + 16 * material;
                     const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
-                    const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-                    if (stack_in_lds) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
+                    const int owner = -2 - pix;
+                    stack_lds[wave][level][owner] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    atomicSub(&outstanding[wave][owner], 1);
+                    pix = -1;
+                } else if (lit || has_helper) {                 // src/main.cpp:85-102
+                    if (lit) {
+                        const float* m = sc.mats + 16 * material;
+                        const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
+                        const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                        if (stack_in_lds) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
+                    }
                     if (level < f.max_depth) {
                         const f3 V = normalize3(-rayDir);
                         const f3 R = (2.0f * dot3(V, N) * N) - V;
@@ -121,6 +183,12 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     phase = 1 + next_light;
                     begin = true;
                 }
+                if (path_end && helpers && atomicAdd(&outstanding[wave][lane], 0) != 0) {
+                    // a helper still traces shadow rays for this path: fold when it has reported
+                    phase = top == level ? -1 : -2;
+                    w.state = 2;
+                    path_end = false;
+                }
                 if (path_end) {
                     f3 C = mk(0, 0, 0);
                     const auto fold = [&](const float4 s4) {
@@ -130,6 +198,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     // one loop per address space (the choice is uniform over the launch): a pointer selected inside a
                     // single loop would turn every read into a flat load
                     if (stack_in_lds) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         const __attribute__((address_space(3))) float* sl =
                             (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
                         for (int d = top; d >= 0; d--) fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
@@ -141,10 +210,11 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     f.rgb[3 * pix + 2] = C.z;
                     if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
                     pix = -1;
+                    phase = 0;
                 }
             }
             // lanes without a path draw the next pixels
-            const bool idle = pix < 0;
+            const bool idle = pix == -1;
             const unsigned long long idle_mask = __ballot(idle);
             if (!exhausted && idle_mask != 0) {
                 const int n_idle = __popcll(idle_mask);
@@ -183,9 +253,10 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
             }
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
-            if (exhausted && !__any(pix >= 0)) break;
+            if (exhausted && !__any(pix != -1)) break;
         }
-        if (__any(pix >= 0 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
+        if (__any(pix != -1 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
+        if (++guard > (1 << 22)) break;
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
     if (COUNT) flush_work(wc, f.work);
