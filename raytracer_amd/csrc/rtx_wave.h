@@ -113,7 +113,8 @@ struct Walker {
     int cur_w;
     uint2 cur;
     int state;           // 0: about to enter coarse cell (ix,iy,iz); 1: standing on fine cell (lx,ly,lz), not looked
-                         // at yet; 3: done with that fine cell, leaves it at the next step; 2: finished
+                         // at yet; 3: done with that fine cell, leaves it at the next step; 4: done with the coarse
+                         // cell, leaves it at the next step; 2: finished
     bool hit;
 
     // collidesWithBox + start cell + first crossings (src/grid.h:91-138,156-227); same arithmetic as traverse()
@@ -193,12 +194,13 @@ struct Walker {
         if (done) { state = 2; hit = true; }
         else if (beyond || outside) {
             if (found) { state = 2; hit = true; }
-            else coarse_advance(g);
+            else state = 4;
         }
     }
 
-    // Walks until the lane stands on a candidate list (returns true and fills start/count), finishes, or has
-    // used `budget` steps.  Every step either finishes the ray or moves a cell index monotonically toward the
+    // Walks until the lane stands on a candidate list, finishes, or has used `budget` steps.  Returns true on a
+    // list: start/count are the list's range for the reference lists; for the nested search start is the number
+    // of the occupied fine cell, whose range the caller reads (all lanes at once, after the loop).  Every step either finishes the ray or moves a cell index monotonically toward the
     // grid boundary, so the walk terminates.
     template <bool COUNT>
     __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, const Occupancy& occ, int budget, int& start,
@@ -208,6 +210,7 @@ struct Walker {
             // one step = leave the fine cell that is done with, enter a coarse cell if the walk stands before one,
             // look at the fine cell the walk stands on: the only copy of each piece of the walk in the kernel
             if (MODE == RT_SEARCH_NESTED && state == 3) fine_advance(g, found, best_t);
+            if (state == 4) coarse_advance(g);
             if (state == 0) {
                 if (COUNT) wc.cell_steps++;
                 t_exit = min_of4(nx, ny, nz, t_limit);
@@ -217,7 +220,7 @@ struct Walker {
                 if (MODE == RT_SEARCH_REF) {
                     const int b = g.cstart[cell], e = g.cstart[cell + 1];
                     if (e > b) { start = b; count = e - b; return true; }
-                    coarse_advance(g);
+                    state = 4;
                 } else if (occ.test(cell)) {
                     const int k = g.sub;
                     const f3 p = O + fmaxf(t_in, 0.0f) * D;
@@ -236,7 +239,7 @@ struct Walker {
                     word_base = __mul24(cell, sp.words_per_block);
                     state = 1;
                 } else {
-                    coarse_advance(g);
+                    state = 4;
                 }
             }
             if (MODE == RT_SEARCH_NESTED && state == 1) {
@@ -247,9 +250,8 @@ struct Walker {
                 if (w != cur_w) { cur = sp.words[w]; cur_w = w; }
                 const unsigned bit = 1u << (local & 31);
                 if (cur.x & bit) {
-                    const int o = (int)cur.y + __popc(cur.x & (bit - 1u));
-                    const int b = sp.ostart[o], e = sp.ostart[o + 1];
-                    start = b; count = e - b;
+                    start = (int)cur.y + __popc(cur.x & (bit - 1u));
+                    count = 1;
                     return true;
                 }
                 state = 3;
@@ -262,7 +264,7 @@ struct Walker {
     __device__ __forceinline__ void after_tests(const DevGrid& g, bool found, float best_t, bool any_hit) {
         if (MODE == RT_SEARCH_REF) {
             if (found) { state = 2; hit = true; }
-            else coarse_advance(g);
+            else state = 4;
         } else {
             if (found && any_hit) { state = 2; hit = true; }
             else state = 3;                 // the next step leaves the cell, knowing found / best_t
@@ -393,6 +395,10 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
     const bool pending = w.template walk<COUNT>(g, sp, occ, budget, start, count, r.found, r.best_t, wc);
     if (!pending) count = 0;
+    else if (MODE == RT_SEARCH_NESTED) {
+        const int b = sp.ostart[start], e = sp.ostart[start + 1];
+        start = b; count = e - b;
+    }
     const int incl = wave_inclusive_scan(count);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     const unsigned long long c1 = COUNT ? __builtin_readcyclecounter() : 0ull;
