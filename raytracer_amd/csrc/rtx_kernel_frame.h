@@ -53,6 +53,9 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     // once, and the chain of dependent rays of a depth-5 path shrinks from 12 to 7.  The helper writes the level's
     // term into the path's slot; a path folds only when all its helpers have reported (pending_helpers).
     const bool helpers = f.helpers != 0 && stack_in_lds;
+    typedef float4 __attribute__((may_alias)) float4_any;
+    static_assert(sizeof(l.cand_who) >= 64 * sizeof(float4) && offsetof(WaveLds, cand_who) % 16 == 0, "hand-over slots");
+    float4_any* const hand_over = reinterpret_cast<float4_any*>(l.cand_who);   // 64 float4 in the ring's second array
     outstanding[wave][lane] = 0;
     int guard = 0;                                      // bounds the loop whatever happens: a frame needs a few thousand rounds
 
@@ -120,16 +123,17 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const int req_rank = __popcll(req_mask & below), idle_rank = __popcll(idle_mask & below);
                     if (want_helper && req_rank < n_match) {
-                        l.ray_a[req_rank] = make_float4(P.x, P.y, P.z, as_float(material));
-                        l.ray_b[req_rank] = make_float4(N.x, N.y, N.z, as_float(level));
-                        l.cand_n[req_rank] = make_float4(rayDir.x, rayDir.y, rayDir.z, as_float(lane));
+                        // (the candidate ring is free between rounds; the ray slots are not, they hold the rays in flight)
+                        l.cand_n[req_rank] = make_float4(P.x, P.y, P.z, as_float(material));
+                        l.cand_n[64 + req_rank] = make_float4(N.x, N.y, N.z, as_float(level));
+                        hand_over[req_rank] = make_float4(rayDir.x, rayDir.y, rayDir.z, as_float(lane));
                         atomicAdd(&outstanding[wave][lane], 1);
                         has_helper = true;
                         next_light = -1;
                     }
                     wave_lds_sync();
                     if (!alive && idle_rank < n_match) {
-                        const float4 a = l.ray_a[idle_rank], b = l.ray_b[idle_rank], c = l.cand_n[idle_rank];
+                        const float4 a = l.cand_n[idle_rank], b = l.cand_n[64 + idle_rank], c = hand_over[idle_rank];
                         P = mk(a.x, a.y, a.z); material = as_int(a.w);
                         N = mk(b.x, b.y, b.z); level = as_int(b.w);
                         rayDir = mk(c.x, c.y, c.z);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                 }
                 if (base + n_idle >= n_items) exhausted = true;
             }
-            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, tl, wc);
+            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, xf, l, w, r, O, D, tl, wc);
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             if (exhausted && !__any(pix != -1)) break;
         }

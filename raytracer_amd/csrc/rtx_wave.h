@@ -366,16 +366,27 @@ struct LaneSearch {
     int best_prim;
 };
 
-// Starts a new ray on the calling lanes (others keep theirs).  May be called under divergence.
+// Starts a new ray on the calling lanes (others keep theirs).  May be called under divergence.  The ray in the
+// space the tests run in goes to the lane's LDS slot here, once: with a single transform in the scene it is taken to
+// object space from the matrix held in scalar registers (src/geometries.h:179-180, same arithmetic for every
+// primitive); the rounds only add the acceptance bound and the list position (the w components).
 template <int MODE, bool SINGLE_XF, bool COUNT>
-__device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, WaveLds& l, Walker<MODE>& w, LaneSearch& r, f3 O, f3 D,
-                                          float t_limit, WorkCounters& wc) {
+__device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, const XfRegs& xf, WaveLds& l, Walker<MODE>& w, LaneSearch& r,
+                                          f3 O, f3 D, float t_limit, WorkCounters& wc) {
     w.init(g, O, D, t_limit, true);
     if (COUNT) { wc.rays++; if (SINGLE_XF) wc.xform_evals++; }
     r.found = false;
     r.best_t = FLT_MAX;
     r.best_prim = -1;
-    l.best[lane_id()] = RT_BEST_NONE;
+    const int lane = lane_id();
+    l.best[lane] = RT_BEST_NONE;
+    f3 Or = O, Dr = D;
+    if (SINGLE_XF) {
+        Or = xf_point(xf, O);
+        Dr = xf_dir(xf, D);
+    }
+    l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, 0.0f);
+    l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, 0.0f);
 }
 
 // One round for the whole wave: every lane with an unfinished ray walks to its next candidate list, the
@@ -404,15 +415,9 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     const unsigned long long c1 = COUNT ? __builtin_readcyclecounter() : 0ull;
     if (total > 0) {
         const int excl = incl - count;
-        // the ray in the space the tests run in: with a single transform in the scene it is taken to object space
-        // here, once per round, from the matrix held in scalar registers (same arithmetic, same bits every time)
-        f3 Or = w.O, Dr = w.D;
-        if (SINGLE_XF) {
-            Or = xf_point(xf, w.O);
-            Dr = xf_dir(xf, w.D);
-        }
-        l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, w.t_exit);
-        l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, as_float(start - excl));
+        // the ray itself has been in the lane's slot since ray_begin
+        l.ray_a[lane].w = w.t_exit;
+        l.ray_b[lane].w = as_float(start - excl);
         int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
         int q_head = 0, q_tail = 0;                  // ring positions of the queued triangle candidates (wave-uniform)
         for (int base = 0; base < total; base += 64) {
@@ -484,7 +489,7 @@ __device__ bool trace_wave(const DevScene& sc, const DevGrid& g, const DevSparse
     LaneSearch r;
     w.init(g, O, D, t_limit, false);
     r.found = false; r.best_t = FLT_MAX; r.best_prim = -1;
-    if (active) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, l, w, r, O, D, t_limit, wc);
+    if (active) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, xf, l, w, r, O, D, t_limit, wc);
     while (__any(w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT>(sc, g, sp, occ, xf, l, w, r, ANY, MODE == RT_SEARCH_REF ? 4 : 8, wc);
     t_hit = r.best_t;
     prim_hit = r.best_prim;
