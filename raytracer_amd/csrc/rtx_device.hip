@@ -28,11 +28,11 @@
 
 using namespace rt;
 
+// traced-window pixels per resident lane from which the frame kernel runs with four waves per SIMD
+#define RTX_PIXELS_PER_LANE_FOR_4_WAVES 10.0
+
 #define RTX_MAX_LEVELS 16          // max_depth <= 15
 #define RTX_BLOCK 256
-#ifndef RTX_FRAME_WAVES_PER_SIMD
-#define RTX_FRAME_WAVES_PER_SIMD 3      // occupancy the persistent kernel's register allocation is held to
-#endif
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -253,26 +253,32 @@ void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level
     if (timed) (void)hipEventRecord(ev[2], st);
 }
 
-template <int MODE, bool SINGLE_XF, int PRIMS>
-void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
+template <int MODE, bool SINGLE_XF, int PRIMS, int WAVES>
+void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
     float4* ps = c->path_stack.p;
-    if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
-    else hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, false, PRIMS>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+    if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+    else hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+}
+
+template <int MODE, bool SINGLE_XF, int PRIMS>
+void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels, int waves) {
+    if (waves >= 4) launch_frame4<MODE, SINGLE_XF, PRIMS, 4>(c, sc, f, blocks, st, count, levels);
+    else launch_frame4<MODE, SINGLE_XF, PRIMS, 3>(c, sc, f, blocks, st, count, levels);
 }
 
 // picks the kernel specialisation for the scene: one transform or many, triangles only / spheres only / both
 template <int MODE>
-void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
+void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels, int waves) {
     const bool single = c->n_xforms == 1;
     const int prims = c->n_spheres == 0 ? 1 : (c->n_triangles == 0 ? 2 : 0);
     if (single) {
-        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, blocks, st, count, levels);
-        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, blocks, st, count, levels);
-        else launch_frame3<MODE, true, 0>(c, sc, f, blocks, st, count, levels);
+        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, blocks, st, count, levels, waves);
+        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, blocks, st, count, levels, waves);
+        else launch_frame3<MODE, true, 0>(c, sc, f, blocks, st, count, levels, waves);
     } else {
-        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, blocks, st, count, levels);
-        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, blocks, st, count, levels);
-        else launch_frame3<MODE, false, 0>(c, sc, f, blocks, st, count, levels);
+        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, blocks, st, count, levels, waves);
+        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, blocks, st, count, levels, waves);
+        else launch_frame3<MODE, false, 0>(c, sc, f, blocks, st, count, levels, waves);
     }
 }
 
@@ -694,6 +700,14 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     // nested search, persistent kernel: only the tiles of the window that can see an occupied fine cell are traced
     const int tbx = (p->width + 7) / 8, tby = (p->height + 7) / 8;
     const int n_row_blocks = f.n_items0 > 0 ? (lr_end - f.lr0 + 7) / 8 : 0;
+    // Register budget of the frame kernel: with many pixels of the traced window per lane of the launch the frame is
+    // bound by throughput and four waves per SIMD win (measured on scene7: 4K frame 2.16 against 2.35 ms); with few
+    // it is a handful of chains of dependent rays per lane and the version with more registers per lane finishes
+    // each ray sooner (1440p and below, an eighth of a 4K frame).  A launch of one workgroup per CU (several frames
+    // in flight) gains no residency from the smaller budget.
+    const double pixels_per_lane = (double)f.n_items0 / ((double)blocks * RTX_BLOCK);
+    int frame_waves = pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_4_WAVES && blocks >= 2 * c->n_cus ? 4 : 3;
+    if (const char* e = getenv("RTX_FRAME_WAVES")) frame_waves = atoi(e);                       // A/B knob
     bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
     if (const char* e = getenv("RTX_TILE_CULL")) tile_cull = tile_cull && atoi(e) != 0;          // A/B knob
     if (tile_cull) {
@@ -783,8 +797,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     }
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
-        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels);
-        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, blocks, st, count, levels);
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels, frame_waves);
+        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, blocks, st, count, levels, frame_waves);
         HIP_TRY(hipEventRecord(ev[1], st));
     }
     for (int l = 0; level_queues && l < levels; l++) {

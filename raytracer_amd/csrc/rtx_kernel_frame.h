@@ -14,10 +14,20 @@
 // Results are bit-identical to the level-synchronous kernels: every ray and every term is computed by the
 // same code, only the schedule differs.
 // ---------------------------------------------------------------------------------------------------
-#define RTX_LDS_LEVELS 6              // paths up to this many levels keep their per-level terms in LDS
+// Two register budgets are compiled (WAVES = resident waves per SIMD the allocation is held to):
+//   4 waves (128 registers, a few spills in the state update, 39.7 KB of LDS per workgroup so that four fit a CU):
+//     more waves to hide the latencies of a round behind; the faster one when the frame holds many pixels per lane;
+//   3 waves (168 registers, 43.8 KB): shorter time per ray; the faster one when a frame is a few chains of
+//     dependent rays per lane (small images, a rank's share of a frame).
+// The host picks by the number of pixels of the traced window per resident lane.
+template <int WAVES>
+struct FrameBudget {
+    static constexpr int lds_levels = WAVES >= 4 ? 5 : 6;   // path levels whose terms live in LDS (deeper: global)
+};
 
-template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS>
-__global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
+template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
+__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
+    constexpr int RTX_LDS_LEVELS = FrameBudget<WAVES>::lds_levels;
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
@@ -28,8 +38,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
-    // per-level terms of this lane's path: LDS when the depth allows, else a private strip of global memory
-    const bool stack_in_lds = levels <= RTX_LDS_LEVELS;
+    // per-level terms of this lane's path: the first RTX_LDS_LEVELS levels (where nearly all hits are) in LDS, deeper
+    // ones in a private strip of global memory
     float4* stack_g = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
     WorkCounters wc = {};
 
@@ -52,10 +62,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
     // rays of fresh hits (hit record handed over through LDS), the path's own lane goes on with the mirror ray at
     // once, and the chain of dependent rays of a depth-5 path shrinks from 12 to 7.  The helper writes the level's
     // term into the path's slot; a path folds only when all its helpers have reported (pending_helpers).
-    const bool helpers = f.helpers != 0 && stack_in_lds;
-    typedef float4 __attribute__((may_alias)) float4_any;
-    static_assert(sizeof(l.cand_who) >= 64 * sizeof(float4) && offsetof(WaveLds, cand_who) % 16 == 0, "hand-over slots");
-    float4_any* const hand_over = reinterpret_cast<float4_any*>(l.cand_who);   // 64 float4 in the ring's second array
+    const bool helpers = f.helpers != 0;
     outstanding[wave][lane] = 0;
     int guard = 0;                                      // bounds the loop whatever happens: a frame needs a few thousand rounds
 
@@ -96,7 +103,8 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                         atomicAdd(&hit_count[wave][level], 1);
                         if (level == 0 && f.ids) f.ids[pix] = prim;
                         acc = mk(0, 0, 0);
-                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && exhausted; } else lit = true;
+                        // (helpers report through LDS: the few hits of the deep levels keep their shadow rays)
+                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && exhausted && level < RTX_LDS_LEVELS; } else lit = true;
                     }
                 } else {                                        // src/main.cpp:57-75
                     const int li = phase - 1;
@@ -123,21 +131,24 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const int req_rank = __popcll(req_mask & below), idle_rank = __popcll(idle_mask & below);
                     if (want_helper && req_rank < n_match) {
-                        // (the candidate ring is free between rounds; the ray slots are not, they hold the rays in flight)
-                        l.cand_n[req_rank] = make_float4(P.x, P.y, P.z, as_float(material));
-                        l.cand_n[64 + req_rank] = make_float4(N.x, N.y, N.z, as_float(level));
-                        hand_over[req_rank] = make_float4(rayDir.x, rayDir.y, rayDir.z, as_float(lane));
+                        // the hit record goes through the requester's own ray slots (its ray has ended) and the
+                        // candidate ring (idle between rounds); owner_at tells the k-th helper where to look
+                        l.ray_a[lane] = make_float4(P.x, P.y, P.z, as_float(material));
+                        l.ray_b[lane] = make_float4(N.x, N.y, N.z, as_float(level));
+                        l.cand_n[lane] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
+                        l.owner_at[req_rank] = lane;
                         atomicAdd(&outstanding[wave][lane], 1);
                         has_helper = true;
                         next_light = -1;
                     }
                     wave_lds_sync();
                     if (!alive && idle_rank < n_match) {
-                        const float4 a = l.cand_n[idle_rank], b = l.cand_n[64 + idle_rank], c = hand_over[idle_rank];
+                        const int from = l.owner_at[idle_rank];
+                        const float4 a = l.ray_a[from], b = l.ray_b[from], c = l.cand_n[from];
                         P = mk(a.x, a.y, a.z); material = as_int(a.w);
                         N = mk(b.x, b.y, b.z); level = as_int(b.w);
                         rayDir = mk(c.x, c.y, c.z);
-                        pix = -2 - as_int(c.w);
+                        pix = -2 - from;
                         acc = mk(0, 0, 0);
                         next_light = 0;
                         act = true;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                         const float* m = sc.mats + 16 * material;
                         const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
                         const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-                        if (stack_in_lds) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
+                        if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
                     }
                     if (level < f.max_depth) {
                         const f3 V = normalize3(-rayDir);
@@ -199,16 +210,14 @@ __global__ __launch_bounds__(RTX_BLOCK, RTX_FRAME_WAVES_PER_SIMD) void k_frame(D
                         const float* m = sc.mats + 16 * as_int(s4.w);
                         C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
                     };
-                    // one loop per address space (the choice is uniform over the launch): a pointer selected inside a
-                    // single loop would turn every read into a flat load
-                    if (stack_in_lds) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const __attribute__((address_space(3))) float* sl =
-                            (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
-                        for (int d = top; d >= 0; d--) fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
-                    } else {
-                        for (int d = top; d >= 0; d--) fold(stack_g[d]);
-                    }
+                    // one loop per address space: a pointer selected inside a single loop would turn every read into a
+                    // flat load
+                    for (int d = top; d >= RTX_LDS_LEVELS; d--) fold(stack_g[d]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const __attribute__((address_space(3))) float* sl =
+                        (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
+                    for (int d = min(top, RTX_LDS_LEVELS - 1); d >= 0; d--)
+                        fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
                     f.rgb[3 * pix] = C.x;
                     f.rgb[3 * pix + 1] = C.y;
                     f.rgb[3 * pix + 2] = C.z;

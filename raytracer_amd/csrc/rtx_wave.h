@@ -35,10 +35,10 @@ struct __attribute__((aligned(16))) WaveLds {
     unsigned long long best[64];   // (t bits << 32) | primitive, all ones = none
     int owner_at[64];              // per pair slot of the current 64-pair batch: lane whose list starts there, else 0
     // triangle candidates that passed the sign tests and await their divisions (ring of RT_CAND_RING entries)
-    float4 cand_n[128];            // numerators of beta, gamma, t and the common denominator
-    int2 cand_who[128];            // owner lane, primitive index
+    float4 cand_n[64];             // numerators of beta, gamma, t and the common denominator
+    int2 cand_who[64];             // owner lane, primitive index
 };
-#define RT_CAND_RING 128
+#define RT_CAND_RING 64
 
 #define RT_BEST_NONE 0xffffffffffffffffull
 
@@ -445,23 +445,25 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
                 }
             }
             // The divisions are the dearest part of a triangle test and one pair in five gets that far: the
-            // survivors are queued and divided 64 at a time instead of a few per batch.
+            // survivors are queued and divided when the queue cannot take the next batch's, not a few per batch.
             const unsigned long long qm = __ballot(queued);
             if (qm != 0) {
+                const int n_new = __popcll(qm);
+                if (q_tail - q_head + n_new > RT_CAND_RING) {
+                    wave_lds_sync();
+                    finish_candidates(l, q_head, q_tail - q_head);
+                    q_head = q_tail;
+                    wave_lds_sync();
+                }
                 if (queued) {
                     const int at = (q_tail + __popcll(qm & ((1ull << lane) - 1ull))) & (RT_CAND_RING - 1);
                     l.cand_n[at] = cand;
                     l.cand_who[at] = make_int2(owner, cand_pid);
                 }
-                q_tail += __popcll(qm);
-                if (q_tail - q_head >= 64) {
-                    wave_lds_sync();
-                    finish_candidates(l, q_head, 64);
-                    q_head += 64;
-                }
+                q_tail += n_new;
             }
         }
-        if (q_tail > q_head) {                       // at most 63 left
+        if (q_tail > q_head) {                       // at most 64 left
             wave_lds_sync();
             finish_candidates(l, q_head, q_tail - q_head);
         }

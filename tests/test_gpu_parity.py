@@ -443,6 +443,26 @@ def test_schedule_hints_never_change_the_frame(renderer):
                 assert np.array_equal(rgb[rows].view(np.int32), want[1][0][rows].view(np.int32))
 
 
+@pytest.mark.parametrize("name,sub", [("scene4-specular", 0), ("scene5", 0), ("scene6", 0), ("scene7", 6)])
+def test_both_register_budgets_of_the_frame_kernel(renderer, monkeypatch, name, sub):
+    """The frame kernel is compiled for three and for four resident waves per SIMD (168 / 128 registers, six / five
+    path levels in LDS, deeper ones in global memory) and the library picks one by the size of the frame.  Forced
+    either way, at a depth inside the LDS levels and at one beyond them, with and without helpers: the frame equals the
+    level-queue pipeline's bit for bit."""
+    load(renderer, name, sub)
+    W, H = 320, 240
+    for depth in (5, 9):
+        want_rgb, want_ids, _ = renderer.render(W, H, depth, level_queues=True)
+        for waves in ("3", "4"):
+            for helpers in ("1", "0"):
+                monkeypatch.setenv("RTX_FRAME_WAVES", waves)
+                monkeypatch.setenv("RTX_HELPERS", helpers)
+                for _ in range(2):                     # second frame: ordered by the first one's path depths
+                    rgb, ids, _ = renderer.render(W, H, depth)
+                    assert np.array_equal(ids, want_ids), (depth, waves, helpers)
+                    assert np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)), (depth, waves, helpers)
+
+
 def test_command_line_renderer_writes_the_oracles_image(tmp_path):
     """`rt scene.test` stands where the reference's main() stands: parse, render, save.  Its PNG and PPM must hold the
     oracle's frame after the reference's truncating 8-bit conversion; the python `raytrace()` wrapper likewise."""
