@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
+    ap.add_argument("--no-frames-in-flight", action="store_true", help="skip the secondary two-frames-in-flight measurement")
     ap.add_argument("--cpu-row-step", type=int, default=8)
     # rehearsal of the multi-rank control flow on a machine with fewer GPUs than ranks: collectives over gloo on
     # host copies, every rank rendering on GPU 0; never used for reported numbers
@@ -271,6 +272,31 @@ def main():
             "frac_of_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "frac_of_unfused_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_UNFUSED_TFLOPS,
         }
+    # secondary figure: throughput with two frames in flight on one GPU (each frame complete and on its own stream and
+    # device context; the second frame's workgroups take over the CUs that the first frame's last paths leave idle)
+    if world == 1 and not args.no_frames_in_flight:
+        second = rt.Renderer(local_rank)
+        second.set_scene(sr)
+        second.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+        pair = [(r, torch.cuda.Stream(), local[0]), (second, torch.cuda.Stream(), torch.empty_like(local[0]))]
+
+        def overlapped(n):
+            for k in range(n):
+                rr, stream, buf = pair[k % 2]
+                rr.render_device(buf.data_ptr(), 0, W, H, max_depth, search, args.tile_rows, 0, 1, stream=stream.cuda_stream,
+                                 workgroups_per_cu=4)
+        overlapped(2 * max(args.warmup, 1))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        overlapped(args.steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        same = bool(torch.equal(pair[0][2], pair[1][2]))
+        out["two_frames_in_flight"] = {
+            "what": "the same frames, the next one started while the last paths of the current one still run (not the headline: "
+                    "one frame at a time above)",
+            "ms_per_step": ms, "value": total_rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "frames_identical": same}
+        second.close()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.scene, W, H, max_depth, args.cpu_row_step // 2, args.cpu_row_step)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
