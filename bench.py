@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
     ap.add_argument("--no-frames-in-flight", action="store_true", help="skip the secondary two-frames-in-flight measurement")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline measurement and its roofline: no frames without the scheduling hint, no secondary "
+                         "figures, no CPU baseline (what the committed rocprofv3 kernel trace is taken over, so that every "
+                         "launch of the frame kernel in it is one of the measured kind)")
     ap.add_argument("--cpu-row-step", type=int, default=8)
     # rehearsal of the multi-rank control flow on a machine with fewer GPUs than ranks: collectives over gloo on
     # host copies, every rank rendering on GPU 0; never used for reported numbers
@@ -82,6 +86,8 @@ def main():
                     help="what travels to rank 0: the float framebuffer (Image3f, the default) or the 8-bit image the "
                          "reference saves, converted on each GPU before the gather (a quarter of the bytes)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_reference_lists = args.no_frames_in_flight = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,12 +204,12 @@ def main():
     # camera costs): the library reads the switch at every call
     os.environ["RTX_TILE_FEEDBACK"] = "0"
     cold = []
-    for _ in range(5):
+    for _ in range(0 if args.headline_only else 5):
         st_c, _ = frame(want_stats=True)
         cold.append(st_c.frame_ms)
     del os.environ["RTX_TILE_FEEDBACK"]
     frame()
-    cold_ms = float(np.median(cold))
+    cold_ms = float(np.median(cold)) if cold else None
     rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays],
                               dtype=torch.float64, device="cpu" if host_gather else dev)
     if world > 1:
