@@ -121,10 +121,10 @@ def main():
     as_u8 = args.gather == "u8"
     # With more than one rank three frames are in flight, each on its own stream and device context.  A rank's share
     # of a frame is small, its run time is set by the longest chains of dependent rays rather than by the amount of
-    # work; three frames side by side (each kernel launched with a third of the workgroups) fill the GPU, and the
+    # work; three frames side by side (each kernel launched with two workgroups per CU) fill the GPU, and the
     # gather of a frame travels while the next ones render.  One rank renders one frame at a time.
     depth = 3 if world > 1 and not args.sync_gather else 1            # frames in flight
-    wg_per_cu = 0 if depth == 1 else (2 if world == 2 else 1)
+    wg_per_cu = 0 if depth == 1 else 2                                # workgroups per CU of each frame's kernel
     renderers = [r]
     for _ in range(1, depth):
         extra = rt.Renderer(local_rank)
