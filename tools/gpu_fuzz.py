@@ -1,0 +1,54 @@
+"""Development differential run on the GPU box: random scenes (the generator of tests/test_gpu_parity.py) rendered by
+the default pipeline in both builds of the frame kernel, with and without helpers, against the CPU oracle and against
+the level-queue pipeline bit for bit.
+
+    python tools/gpu_fuzz.py [first_seed] [n_seeds]
+"""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import raytracer_amd as rt
+from oracle.ref_oracle import RefScene
+from test_gpu_parity import _random_scene, FLOAT_TOL
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+r = rt.Renderer(0)
+bad = 0
+with tempfile.TemporaryDirectory() as tmp:
+    path = os.path.join(tmp, "random.test")
+    for seed in range(first, first + n):
+        rng = np.random.default_rng(seed)
+        text = _random_scene(rng, int(rng.integers(0, 200)), int(rng.integers(0, 40)), int(rng.integers(0, 4)))
+        open(path, "w").write(text)
+        depth = int(rng.integers(0, 10))
+        rgb_ref, ids_ref, _, cnt = RefScene(path, counting=True).render(0, 0, depth)
+        r.set_scene(rt.SceneReader().readScene(path))
+        r.build_grid(15, int(rng.choice([0, 1, 2, 3, 5, 6])))
+        want_rgb, want_ids, _ = r.render(0, 0, depth, level_queues=True)
+        problems = []
+        if not np.array_equal(want_ids, ids_ref) or np.abs(want_rgb - rgb_ref).max() > FLOAT_TOL:
+            problems.append("levels vs oracle")
+        for waves in ("3", "4"):
+            for helpers in ("1", "0"):
+                os.environ["RTX_FRAME_WAVES"], os.environ["RTX_HELPERS"] = waves, helpers
+                for k in range(2):
+                    rgb, ids, st = r.render(0, 0, depth)
+                    if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
+                        problems.append(f"frame waves={waves} helpers={helpers} pass={k}")
+                    if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
+                        problems.append(f"ray counts waves={waves} helpers={helpers}")
+        if problems:
+            bad += 1
+            print(f"seed {seed}: {problems}", flush=True)
+        elif (seed - first) % 25 == 0:
+            print(f"seed {seed} ok", flush=True)
+print(f"{n} scenes, {bad} with differences")
+r.close()
+sys.exit(1 if bad else 0)
