@@ -665,7 +665,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
     } else {
-        if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24)) ||
+        // (instrumented frames log eight values per wave behind the 24 work counters)
+        if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24 + 8 * (size_t)blocks * (RTX_BLOCK / 64))) ||
             (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * levels)))
             return rc;
     }
@@ -852,6 +853,23 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         } else {
             stats->trace_launches = 1;                 // the persistent frame kernel does everything
             (void)hipEventElapsedTime(&stats->trace_ms, ev[3], ev[1]);
+        }
+        if (count && !level_queues) {
+            // development aid: per-wave log of the instrumented frame kernel as CSV
+            if (const char* path = getenv("RTX_WAVE_LOG")) {
+                const size_t n_waves = (size_t)blocks * (RTX_BLOCK / 64);
+                std::vector<unsigned long long> log(8 * n_waves);
+                HIP_TRY(hipMemcpy(log.data(), c->work.p + 24, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (FILE* fh = fopen(path, "w")) {
+                    fprintf(fh, "wave,start,exhausted,end,rounds,updates,pixels,deepest,helper_tasks\n");
+                    for (size_t k = 0; k < n_waves; k++) {
+                        fprintf(fh, "%zu", k);
+                        for (int j = 0; j < 8; j++) fprintf(fh, ",%llu", log[8 * k + j]);
+                        fprintf(fh, "\n");
+                    }
+                    fclose(fh);
+                }
+            }
         }
         if (count) {
             unsigned long long w[24];

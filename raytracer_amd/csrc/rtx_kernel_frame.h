@@ -65,6 +65,10 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     const bool helpers = f.helpers != 0;
     outstanding[wave][lane] = 0;
     int guard = 0;                                      // bounds the loop whatever happens: a frame needs a few thousand rounds
+    // instrumented build: when the wave started, ran out of new pixels and ended (100 MHz clock), what it did
+    unsigned long long log_start = 0, log_exhausted = 0;
+    int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0, log_tasks = 0;
+    if (COUNT) log_start = wall_clock64();
 
     for (;;) {
         const bool alive = pix != -1;
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
         const int n_alive = __popcll(__ballot(alive));
         const int threshold = exhausted ? min(f.ready_threshold, max(1, (n_alive * f.drain_num) >> 3)) : f.ready_threshold;
         if (!__any(walking) || n_ready >= threshold) {
-            if (COUNT) wc.w_updates++;
+            if (COUNT) { wc.w_updates++; log_updates++; }
             const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
             bool begin = false;
             f3 O = w.O, D = w.D;
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         N = mk(b.x, b.y, b.z); level = as_int(b.w);
                         rayDir = mk(c.x, c.y, c.z);
                         pix = -2 - from;
+                        if (COUNT) log_tasks++;
                         acc = mk(0, 0, 0);
                         next_light = 0;
                         act = true;
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     f.rgb[3 * pix + 1] = C.y;
                     f.rgb[3 * pix + 2] = C.z;
                     if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
+                    if (COUNT) log_deepest = max(log_deepest, top + 1);
                     pix = -1;
                     phase = 0;
                 }
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                             const int tile = lr / f.tile_rows;
                             const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
                             pix = lr * f.W + x;
+                            if (COUNT) log_pixels++;
                             O = f.cam.eye;
                             rayDir = camera_ray(f.cam, x, y);
                             D = normalize3(rayDir);             // src/main.cpp:82
@@ -262,17 +269,35 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         }
                     }
                 }
-                if (base + n_idle >= n_items) exhausted = true;
+                if (base + n_idle >= n_items) {
+                    if (COUNT && !exhausted) log_exhausted = wall_clock64();
+                    exhausted = true;
+                }
             }
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, xf, l, w, r, O, D, tl, wc);
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             if (exhausted && !__any(pix != -1)) break;
         }
+        if (COUNT) log_rounds++;
         if (__any(pix != -1 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
         if (++guard > (1 << 22)) break;
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
-    if (COUNT) flush_work(wc, f.work);
+    if (COUNT) {
+        flush_work(wc, f.work);
+        int pixels = log_pixels, deepest = log_deepest, tasks = log_tasks;
+        for (int off = 32; off > 0; off >>= 1) {
+            pixels += __shfl_down(pixels, off);
+            tasks += __shfl_down(tasks, off);
+            deepest = max(deepest, __shfl_down(deepest, off));
+        }
+        if (lane == 0) {
+            unsigned long long* log = f.work + 24 + 8 * (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave);
+            log[0] = log_start; log[1] = log_exhausted; log[2] = wall_clock64(); log[3] = (unsigned long long)log_rounds;
+            log[4] = (unsigned long long)log_updates; log[5] = (unsigned long long)pixels; log[6] = (unsigned long long)deepest;
+            log[7] = (unsigned long long)tasks;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
