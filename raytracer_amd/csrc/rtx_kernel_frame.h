@@ -17,8 +17,8 @@
 // Two register budgets are compiled (WAVES = resident waves per SIMD the allocation is held to):
 //   4 waves (128 registers, a few spills in the state update, 39.7 KB of LDS per workgroup so that four fit a CU):
 //     more waves to hide the latencies of a round behind; the faster one when the frame holds many pixels per lane;
-//   3 waves (168 registers, 43.8 KB): shorter time per ray; the faster one when a frame is a few chains of
-//     dependent rays per lane (small images, a rank's share of a frame).
+//   3 waves (168 registers, 43.8 KB, record reads issued one batch ahead): shorter time per ray; the faster one when
+//     a frame is a few chains of dependent rays per lane (small images, a rank's share of a frame).
 // The host picks by the number of pixels of the traced window per resident lane.
 template <int WAVES>
 struct FrameBudget {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             if (exhausted && !__any(pix != -1)) break;
         }
         if (COUNT) log_rounds++;
-        if (__any(pix != -1 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
+        if (__any(pix != -1 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS, (WAVES < 4)>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
         if (++guard > (1 << 22)) break;
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);

@@ -272,16 +272,14 @@ struct Walker {
     }
 };
 
-// One test of pair (owner ray, primitive).  SINGLE_XF: the scene has exactly one transform and the LDS holds the
-// ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed by its
-// primitive's inverse here (src/geometries.h:179-180).
+// One test of pair (owner ray, primitive record q0..q2).  SINGLE_XF: the scene has exactly one transform and the LDS
+// holds the ray already in object space; otherwise the LDS holds the world-space ray and the pair is transformed
+// by its primitive's inverse here (src/geometries.h:179-180).  pid < 0: the record is one of the nested grid's
+// per-reference copies, which carry the primitive index where the primitive table carries the material.
 // Returns true for a triangle whose divisions are still to be done (numerators in cand, index in cand_pid).
 template <bool SINGLE_XF, bool COUNT, int PRIMS>
-__device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, const float4* recs,
-                                          int rec, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
-    // recs: the primitive table (rec = pid) or the nested grid's per-reference copies in list order, which carry
-    // the primitive index where the table carries the material (pid < 0 on entry)
-    const float4 q0 = recs[3 * rec], q1 = recs[3 * rec + 1], q2 = recs[3 * rec + 2];
+__device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, float4 q0, float4 q1,
+                                          float4 q2, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
     if (pid < 0) pid = as_int(q2.z);
     if (!SINGLE_XF) {
         const float* m = sc.xinv + 16 * as_int(q2.y);
@@ -397,7 +395,7 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
 // lane whose list starts inside the batch writes its lane number at the slot of its first pair; a running
 // maximum over the slots (owners ascend with the slots), seeded with the owner carried over from the previous
 // batch, gives every slot its owner.
-template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS = 0>
+template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS = 0, bool AHEAD = false>
 __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g, const DevSparse& sp, const Occupancy& occ, const XfRegs& xf,
                                            WaveLds& l, Walker<MODE>& w, LaneSearch& r, bool any_hit, int budget, WorkCounters& wc) {
     const int lane = lane_id();
@@ -420,29 +418,42 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
         l.ray_b[lane].w = as_float(start - excl);
         int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
         int q_head = 0, q_tail = 0;                  // ring positions of the queued triangle candidates (wave-uniform)
-        for (int base = 0; base < total; base += 64) {
-            if (COUNT) wc.w_test_batches++;
+        // Owner lookup and record reads of the batch that starts at pair `base`.  With AHEAD the loop below issues
+        // them one batch ahead, so that the reads of the next batch travel while the current one is computed: worth
+        // 3 to 8 % where a frame is bound by the latency of its rays (small images, a rank's share), a loss of 5 %
+        // where it is bound by throughput (the registers that hold the second batch).
+        const auto fetch = [&](int base, int& owner, int& pid, float4& q0, float4& q1, float4& q2) {
             l.owner_at[lane] = 0;
             wave_lds_sync();
             if (count > 0 && excl >= base && excl < base + 64) l.owner_at[excl - base] = lane;
             wave_lds_sync();                         // also publishes ray_a / ray_b before the first batch reads them
-            const int owner = max(wave_inclusive_max(l.owner_at[lane]), carry);
+            owner = max(wave_inclusive_max(l.owner_at[lane]), carry);
             carry = __builtin_amdgcn_readlane(owner, 63);
             const int p = base + lane;
+            pid = -1;
+            if (p < total) {
+                int rec = as_int(l.ray_b[owner].w) + p;       // position in the concatenated cell lists
+                const float4* recs = g.frecs;                // the nested grid's copies of the records, in list order
+                if (MODE == RT_SEARCH_REF) { pid = rec = g.cids[rec]; recs = sc.prims; }
+                q0 = recs[3 * rec]; q1 = recs[3 * rec + 1]; q2 = recs[3 * rec + 2];
+            }
+        };
+        int owner = 0, pid = -1;
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+        if (AHEAD) fetch(0, owner, pid, q0, q1, q2);
+        for (int base = 0; base < total; base += 64) {
+            if (COUNT) wc.w_test_batches++;
+            int owner_n = 0, pid_n = -1;
+            float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+            if (!AHEAD) fetch(base, owner, pid, q0, q1, q2);
+            else if (base + 64 < total) fetch(base + 64, owner_n, pid_n, n0, n1, n2);
             bool queued = false;
             float4 cand = make_float4(0, 0, 0, 0);
             int cand_pid = -1;
-            if (p < total) {
+            if (base + lane < total) {
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
-                const int at = as_int(rb.w) + p;             // position in the concatenated cell lists
-                if (MODE == RT_SEARCH_REF) {
-                    const int pid = g.cids[at];
-                    queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, sc.prims, pid, pid,
-                                                                cand, cand_pid, wc);
-                } else {
-                    queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, g.frecs, at, -1,
-                                                                cand, cand_pid, wc);
-                }
+                queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, q0, q1, q2, pid,
+                                                            cand, cand_pid, wc);
             }
             // The divisions are the dearest part of a triangle test and one pair in five gets that far: the
             // survivors are queued and divided when the queue cannot take the next batch's, not a few per batch.
@@ -461,6 +472,10 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
                     l.cand_who[at] = make_int2(owner, cand_pid);
                 }
                 q_tail += n_new;
+            }
+            if (AHEAD) {
+                owner = owner_n; pid = pid_n;
+                q0 = n0; q1 = n1; q2 = n2;
             }
         }
         if (q_tail > q_head) {                       // at most 64 left
