@@ -304,6 +304,24 @@ def test_bench_two_ranks_rehearsal(gather, extra):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+def test_bench_eight_ranks_rehearsal():
+    """The 8-rank control flow of bench.py (six frames in flight per rank, 8-row tiles that do not divide evenly among
+    the ranks) with eight processes sharing the one GPU over gloo: the reassembled frame equals the single-rank one."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "13", "--warmup", "2", "--width", "640",
+           "--height", "360", "--backend", "gloo", "--share-gpu", "--check-image", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["image_check"] is True
+    assert "6 frame(s) in flight" in out["config"]["workload"]
+    assert out["config"]["rays_per_frame"]["primary"] == 640 * 360
+
+
 @pytest.mark.parametrize("n_pixels", [0, 1, 3, 4, 5, 1023, 160 * 120, 3840 * 2160])
 def test_device_quantise_matches_host_rule(renderer, n_pixels):
     """(unsigned char)(clamp(c) * 255) on the device, both channel orders, against the host conversion (which the CPU
