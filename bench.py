@@ -186,6 +186,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # every slot's device context renders its first two frames here (its allocations, its first scheduling hint), so that
+    # the W warm-up frames and the timed ones meet the same state whichever slot they fall on
+    for b in range(depth if depth > 1 else 0):
+        with torch.cuda.stream(streams[b]):
+            for _ in range(2):
+                render(b, wg=wg_per_cu)
+    sync()
     frames(args.warmup)
     sync()
     t0 = time.perf_counter()
