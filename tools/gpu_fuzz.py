@@ -31,19 +31,21 @@ with tempfile.TemporaryDirectory() as tmp:
         rgb_ref, ids_ref, _, cnt = RefScene(path, counting=True).render(0, 0, depth)
         r.set_scene(rt.SceneReader().readScene(path))
         r.build_grid(15, int(rng.choice([0, 1, 2, 3, 5, 6])))
-        want_rgb, want_ids, _ = r.render(0, 0, depth, level_queues=True)
         problems = []
-        if not np.array_equal(want_ids, ids_ref) or np.abs(want_rgb - rgb_ref).max() > FLOAT_TOL:
-            problems.append("levels vs oracle")
-        for waves in ("3", "4"):
-            for helpers in ("1", "0"):
-                os.environ["RTX_FRAME_WAVES"], os.environ["RTX_HELPERS"] = waves, helpers
-                for k in range(2):
-                    rgb, ids, st = r.render(0, 0, depth)
-                    if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
-                        problems.append(f"frame waves={waves} helpers={helpers} pass={k}")
-                    if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
-                        problems.append(f"ray counts waves={waves} helpers={helpers}")
+        for mode, mode_name in ((rt.SEARCH_NESTED, "nested"), (rt.SEARCH_REFERENCE_LISTS, "reference lists")):
+            os.environ.pop("RTX_FRAME_WAVES", None)
+            want_rgb, want_ids, _ = r.render(0, 0, depth, mode, level_queues=True)
+            if not np.array_equal(want_ids, ids_ref) or np.abs(want_rgb - rgb_ref).max() > FLOAT_TOL:
+                problems.append(f"{mode_name}: levels vs oracle")
+            for waves in ("3", "4"):
+                for helpers in ("1", "0"):
+                    os.environ["RTX_FRAME_WAVES"], os.environ["RTX_HELPERS"] = waves, helpers
+                    for k in range(2):
+                        rgb, ids, st = r.render(0, 0, depth, mode)
+                        if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
+                            problems.append(f"{mode_name}: frame waves={waves} helpers={helpers} pass={k}")
+                        if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
+                            problems.append(f"{mode_name}: ray counts waves={waves} helpers={helpers}")
         if problems:
             bad += 1
             print(f"seed {seed}: {problems}", flush=True)
