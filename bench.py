@@ -17,7 +17,8 @@ import time
 
 # Frames in flight run on separate HIP streams; a process gets 4 hardware queues by default and streams beyond that
 # share one, which serialises their kernels.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import numpy as np
 import torch

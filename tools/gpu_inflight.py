@@ -5,6 +5,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8 and "KEEP_HW_QUEUES" not in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"        # as bench.py does: streams beyond the hardware queues share one
 import torch
 
 import raytracer_amd as rt
