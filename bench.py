@@ -6,6 +6,13 @@ One "step" is one full frame: every rank renders its interleaved row tiles of th
 grid and all queues are resident in HBM before the timed region; the timed region is K frames between
 barrier + synchronize pairs, maximum over ranks.  Total work per step is fixed, so scaling is "strong".
 
+Every timed frame is rendered as a first frame: the renderer's scheduling hint from the previous frame of the same
+camera (an ordering of the screen tiles, never a result) is switched off, because the reference renders one frame
+per process.  The rate with the hint is reported beside it (`with_previous_frame_hint`).  `value` counts the
+reference's rays (one camera ray per pixel, one shadow ray per light and one mirror ray per hit); camera rays that
+cannot meet any primitive are answered by a fill instead of a grid walk, so the rays that walked the grid and their
+rate are reported at top level too (`rays_walked`, `Mrays_walked_per_s`).
+
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
@@ -15,9 +22,19 @@ import os
 import sys
 import time
 
+
+
+def _frames_in_flight(world, sync_gather):
+    """One rank renders one frame at a time; with more ranks several frames are in flight (see main())."""
+    return 1 if world == 1 or sync_gather else (3 if world < 8 else 6)
+
+
 # Frames in flight run on separate HIP streams; a process gets 4 hardware queues by default and streams beyond that
-# share one, which serialises their kernels.  Must be set before the HIP runtime starts.
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8:
+# share one, which serialises their kernels.  Only a run that really keeps more than four frames in flight asks for
+# more, only when the operator has not set the variable, and before the HIP runtime starts; the effective value goes
+# into the JSON line.
+if (_frames_in_flight(int(os.environ.get("WORLD_SIZE", "1")), "--sync-gather" in sys.argv) > 4
+        and "GPU_MAX_HW_QUEUES" not in os.environ):
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import numpy as np
@@ -32,6 +49,7 @@ from raytracer_amd.multi_gpu import FrameGather  # noqa: E402
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 128 lanes x 2 (FMA) x 2.4 GHz
 PEAK_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 4   # IEEE mul/add kept separate and unpacked: 1 flop/lane/clk
+PEAK_PACKED_UNFUSED_TFLOPS = PEAK_FP32_VALU_TFLOPS / 2   # separate mul/add, two lanes' worth per packed instruction
 PEAK_HBM_GBS = 8000.0
 
 
@@ -80,7 +98,7 @@ def main():
                     help="only the headline measurement and its roofline: no frames without the scheduling hint, no secondary "
                          "figures, no CPU baseline (what the committed rocprofv3 kernel trace is taken over, so that every "
                          "launch of the frame kernel in it is one of the measured kind)")
-    ap.add_argument("--cpu-row-step", type=int, default=8)
+    ap.add_argument("--cpu-row-step", type=int, default=16)
     # rehearsal of the multi-rank control flow on a machine with fewer GPUs than ranks: collectives over gloo on
     # host copies, every rank rendering on GPU 0; never used for reported numbers
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
@@ -131,7 +149,7 @@ def main():
     # frames in flight and workgroups per CU of each frame's kernel.  An eighth of a frame takes 1.4 ms however many
     # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (measured on one GPU,
     # no gather: 0.33 ms per frame against 0.51 with three frames, 0.75 with two)
-    depth = 1 if world == 1 or args.sync_gather else (3 if world < 8 else 6)
+    depth = _frames_in_flight(world, args.sync_gather)
     wg_per_cu = 0 if depth == 1 else (2 if depth == 3 else 1)
     renderers = [r]
     for _ in range(1, depth):
@@ -147,34 +165,35 @@ def main():
     staged = [torch.empty_like(fg.local_view(b), device=dev) if host_gather else fg.local_view(b) for b in range(depth)]
     local = [torch.empty(tuple(t.shape), dtype=torch.float32, device=dev) if as_u8 else t for t in staged]
 
-    def render(slot=0, want_stats=False, count=False, mode=search, wg=0):
-        """Enqueues this rank's rows of one frame on the slot's stream (the caller has made it current)."""
+    def render(slot=0, want_stats=False, count=False, mode=search, wg=0, hint=False):
+        """Enqueues this rank's rows of one frame on the slot's stream (the caller has made it current).  hint=False:
+        the frame is scheduled as a first frame (no tile order from the previous frame)."""
         stream = streams[slot].cuda_stream
         rr = renderers[slot]
         st = rr.render_device(local[slot].data_ptr(), 0, W, H, max_depth, mode, args.tile_rows, rank, world, stream=stream,
-                              want_stats=want_stats, count_work=count, workgroups_per_cu=wg)
+                              want_stats=want_stats, count_work=count, workgroups_per_cu=wg, tile_hint=hint)
         if as_u8:
             rr.quantize_device(local[slot].data_ptr(), local[slot].shape[0] * W, staged[slot].data_ptr(), stream=stream)
         if host_gather:
             fg.local_view(slot).copy_(staged[slot])
         return st
 
-    def frame(want_stats=False, count=False, mode=search):
+    def frame(want_stats=False, count=False, mode=search, hint=False):
         """One complete frame on slot 0: render, exchange, assemble (nothing left in flight)."""
         with torch.cuda.stream(streams[0]):
-            st = render(0, want_stats, count, mode)
+            st = render(0, want_stats, count, mode, hint=hint)
             img = fg.gather(0)
         streams[0].synchronize()
         return st, img
 
-    def frames(n):
+    def frames(n, hint=False):
         """n frames back to back; a slot's exchange is completed when the slot is needed again."""
         for k in range(n):
             b = k % depth
             with torch.cuda.stream(streams[b]):
                 if fg.in_flight(b):
                     fg.finish(b)
-                render(b, wg=wg_per_cu)
+                render(b, wg=wg_per_cu, hint=hint)
                 fg.gather_async(b)
         for b in range(depth):
             with torch.cuda.stream(streams[b]):
@@ -205,6 +224,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    # the same loop with the previous frame's scheduling hint (a camera that stands still or moves a little)
+    hinted_ms = None
+    if not args.headline_only:
+        frames(max(args.warmup, 2), hint=True)
+        sync()
+        t0 = time.perf_counter()
+        frames(args.steps, hint=True)
+        sync()
+        hinted = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([hinted], dtype=torch.float64, device="cpu" if host_gather else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hinted = float(t.item())
+        hinted_ms = hinted / args.steps * 1e3
 
     # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames)
     st_count, _ = frame(want_stats=True, count=True)
@@ -215,22 +248,13 @@ def main():
         st_t, _ = frame(want_stats=True)
         kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
     kern = np.mean(np.array(kern), axis=0)
-    # the same frame without the scheduling hint of the previous frame (what a first frame or a cut to another
-    # camera costs): the library reads the switch at every call
-    os.environ["RTX_TILE_FEEDBACK"] = "0"
-    cold = []
-    for _ in range(0 if args.headline_only else 5):
-        st_c, _ = frame(want_stats=True)
-        cold.append(st_c.frame_ms)
-    del os.environ["RTX_TILE_FEEDBACK"]
-    frame()
-    cold_ms = float(np.median(cold)) if cold else None
-    rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays],
+    rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays, st_count.traced_primary_rays],
                               dtype=torch.float64, device="cpu" if host_gather else dev)
     if world > 1:
         dist.all_reduce(rays_local)
     rays = [int(v) for v in rays_local.tolist()]
-    total_rays = sum(rays)
+    total_rays = sum(rays[:3])
+    walked_rays = rays[3] + rays[1] + rays[2]
 
     out = None
     if rank == 0:
@@ -247,6 +271,7 @@ def main():
             "kernel": "k_frame (persistent: camera rays, coarse + nested 3D-DDA, triangle/sphere tests, shadow and mirror "
                       "rays, Blinn-Phong, fold), 1 launch per frame, figures are per launch on rank 0",
             "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+            "frac_of_packed_unfused_peak": achieved / PEAK_PACKED_UNFUSED_TFLOPS, "peak_packed_unfused": PEAK_PACKED_UNFUSED_TFLOPS,
             "frac_of_unfused_peak": achieved / PEAK_UNFUSED_TFLOPS, "peak_unfused": PEAK_UNFUSED_TFLOPS,
             "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern[1],
             "work_per_launch": dict(zip(("tri_tests", "sphere_tests", "xform_evals", "cell_steps", "fine_steps",
@@ -268,14 +293,23 @@ def main():
             "metric": "Mrays/sec (primary+shadow+reflection) on scene7 @4K", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "rays_walked": walked_rays, "Mrays_walked_per_s": walked_rays / (ms_per_step * 1e-3) / 1e6,
+            "frame_schedule": "every timed frame is a first frame: no tile order from a previous frame",
+            "with_previous_frame_hint": None if hinted_ms is None else {
+                "ms_per_step": hinted_ms, "value": total_rays / (hinted_ms * 1e-3) / 1e6,
+                "Mrays_walked_per_s": walked_rays / (hinted_ms * 1e-3) / 1e6,
+                "what": "the same loop with the screen tiles ordered by the path depths the previous frame of the same "
+                        "camera recorded (order only; every ray of every frame is traced)"},
+            "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4)"),
             "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
             "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {max_depth}, 15^3 grid, search={args.search}, "
                                    f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "
-                                   f"{args.gather} gather to rank 0, {depth} frame(s) in flight",
-                       "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays},
-                       "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1], "frame_without_previous_frame_hint": cold_ms},
-                       "schedule": "screen tiles that can see geometry, ordered by the path depths the previous frame "
-                                   "recorded per tile (order only; every ray of every frame is traced)",
+                                   f"{args.gather} gather to rank 0, {depth} frame(s) in flight, every frame scheduled as a "
+                                   f"first frame; {walked_rays} of the {total_rays} rays walk the grid (camera rays "
+                                   f"through screen tiles that see no geometry are filled)",
+                       "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays,
+                                          "primary_walked": rays[3], "primary_filled": rays[0] - rays[3]},
+                       "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1]},
                        "grid": {"refs_reference_lists": gi.n_refs, "fine_cells": gi.n_fine_cells,
                                 "refs_fine": gi.n_fine_refs, "build_ms": gi.build_ms}},
             "roofline": roofline,

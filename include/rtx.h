@@ -150,6 +150,17 @@ int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, 
                                       default is one persistent launch per frame (per-wave path pools)        */
 #define RTX_RENDER_SERIAL_LANES 2u /* one lane walks and tests its own ray alone (no sharing of candidate tests
                                       across the wave); same results, kept for A/B timing                     */
+/* Scheduling switches of the persistent frame kernel.  None of them changes a single bit of the frame: they choose
+ * which pixels are answered by a fill instead of a walk, in which order the rest is traced and by which build of the
+ * kernel.  All default to "on" / "automatic" (flag clear). */
+#define RTX_RENDER_NO_TILE_HINT  8u  /* order the screen tiles without the path depths the previous frame of this
+                                        context recorded: what a first frame, or a cut to another camera, costs  */
+#define RTX_RENDER_NO_TILE_CULL 16u  /* trace every 8x8 tile of the screen window, also those that can see no
+                                        occupied fine cell                                                        */
+#define RTX_RENDER_NO_HELPERS   32u  /* a path's own lane traces its shadow rays and its mirror ray one after the
+                                        other, as trace() does (src/main.cpp:85-97)                               */
+#define RTX_RENDER_WAVES_3      64u  /* force the build held to 168 registers (3 waves per SIMD) ...              */
+#define RTX_RENDER_WAVES_4     128u  /* ... or the one held to 128 (4 waves per SIMD); default: chosen by frame size */
 
 typedef struct rtx_render_params {
     int32_t  width, height;        /* full image; y = 0 is the top row (src/main.cpp:127-131)           */
@@ -162,6 +173,14 @@ typedef struct rtx_render_params {
     int32_t  workgroups_per_cu;    /* persistent frame kernel: workgroups launched per compute unit; <= 0 means 4.
                                       A caller that keeps several frames in flight on their own streams and
                                       contexts gives each a share (e.g. 1) so that their kernels run side by side */
+    /* tuning of the persistent frame kernel (results never depend on it); <= 0 selects the default */
+    int32_t  walk_budget;          /* grid steps a lane may take per round (3)                              */
+    int32_t  ready_threshold;      /* lanes with a finished ray that trigger a state update (48)            */
+    int32_t  drain_eighths;        /* ... once no new pixels are left: that many eighths of the live lanes (2) */
+    int32_t  reserved0;
+    int64_t  round_limit;          /* rounds a wave of the frame kernel may run before the frame is abandoned with
+                                      RTX_E_LIMIT; <= 0 derives the bound from the frame (every ray the frame can
+                                      hold times every step a ray can take: no valid frame reaches it)      */
 } rtx_render_params;
 
 typedef struct rtx_stats {
@@ -181,6 +200,13 @@ typedef struct rtx_stats {
                                                  kernel is reported as trace_ms with trace_launches = 1   */
     float   level_trace_ms[16], level_shade_ms[16];   /* the same per level                              */
     int32_t trace_launches, shade_launches, resolve_launches;
+    int32_t reserved0;
+    /* primary_rays counts every pixel of this rank, as the reference casts one camera ray per pixel
+     * (src/main.cpp:126-133).  The persistent frame kernel answers camera rays that cannot meet any primitive
+     * (outside the screen window of the grid box / of every occupied fine cell) with the miss colour without
+     * walking the grid: traced_primary_rays are the camera rays that were walked, culled_pixels the rest
+     * (primary_rays = traced_primary_rays + culled_pixels; every shadow and mirror ray is walked). */
+    int64_t traced_primary_rays, culled_pixels;
 } rtx_stats;
 
 /* Number of image rows this rank renders, and their global row numbers (ascending). rows may be NULL. */
@@ -192,12 +218,23 @@ int  rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows);
 int  rtx_render(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                 float* rgb_out, int32_t* prim_id_out, rtx_stats* stats);
 
+/* A frame is abandoned when a wave of the persistent frame kernel exceeds rtx_render_params.round_limit: its
+ * remaining pixels keep the fill colour.  rtx_render and rtx_render_device with `stats` report that as RTX_E_LIMIT
+ * themselves; after an asynchronous rtx_render_device this call waits for the context's last frame and returns
+ * RTX_OK or RTX_E_LIMIT for it (the next render call on the context reports it as well). */
+int  rtx_frame_status(rtx_ctx* ctx);
+
 /* Same, leaving the result on the device: d_rgb_local is n_local_rows*width*3 floats of DEVICE memory,
  * d_prim_id_local (nullable) n_local_rows*width int32, rows in the order rtx_local_rows() reports.
  * Work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT waited for, except that
  * `stats` (nullable) forces a wait at the end of the call so the numbers are final. */
 int  rtx_render_device(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                        float* d_rgb_local, int32_t* d_prim_id_local, void* stream, rtx_stats* stats);
+
+/* Development aid: per-wave log of the last frame rendered with RTX_RENDER_COUNT_WORK by the persistent frame
+ * kernel.  Eight values per wave: start, cursor exhausted, end (100 MHz clock), rounds, state updates, pixels drawn,
+ * deepest level, helper tasks.  out holds 8 * max_waves values; *n_waves receives the number of waves logged. */
+int  rtx_download_wave_log(rtx_ctx* ctx, uint64_t* out, int64_t max_waves, int64_t* n_waves);
 
 /* Single-ray probes for tests: the device evaluates Grid::intersect (src/grid.h:259-261) for n rays.
  * origins/dirs: [n][3] host floats (directions are used as given, not normalised); t_limit: [n] or NULL

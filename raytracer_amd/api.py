@@ -21,6 +21,17 @@ RENDER_COUNT_WORK = 1
 RENDER_SERIAL_LANES = 2
 ORDER_RGB, ORDER_BGR = 0, 1
 RENDER_LEVEL_QUEUES = 4
+RENDER_NO_TILE_HINT = 8
+RENDER_NO_TILE_CULL = 16
+RENDER_NO_HELPERS = 32
+RENDER_WAVES_3 = 64
+RENDER_WAVES_4 = 128
+
+# Scheduling and tuning fields of rtx_render_params applied to every render call of this process unless the call
+# names them itself.  The library reads no environment variables; development tools (tools/) fill this from theirs,
+# and the test suite sets a round limit here so that a kernel that never ends cannot hang the machine.
+DEFAULTS = dict(tile_hint=True, tile_cull=True, helpers=True, frame_waves=0, walk_budget=0, ready_threshold=0,
+                drain_eighths=0, round_limit=0)
 
 
 class RtxError(RuntimeError):
@@ -49,7 +60,9 @@ class GridInfo(C.Structure):
 class _RenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32), ("eps_bias", C.c_float),
                 ("search", C.c_int32), ("tile_rows", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("flags", C.c_uint32), ("workgroups_per_cu", C.c_int32)]
+                ("flags", C.c_uint32), ("workgroups_per_cu", C.c_int32),
+                ("walk_budget", C.c_int32), ("ready_threshold", C.c_int32), ("drain_eighths", C.c_int32),
+                ("reserved0", C.c_int32), ("round_limit", C.c_int64)]
 
 
 class RenderStats(C.Structure):
@@ -61,11 +74,17 @@ class RenderStats(C.Structure):
                 ("trace_work", C.c_int64 * 8), ("shade_work", C.c_int64 * 8), ("wave_events", C.c_int64 * 4), ("wave_cycles", C.c_int64 * 4),
                 ("frame_ms", C.c_float), ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("resolve_ms", C.c_float),
                 ("level_trace_ms", C.c_float * 16), ("level_shade_ms", C.c_float * 16),
-                ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("resolve_launches", C.c_int32)]
+                ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("resolve_launches", C.c_int32),
+                ("reserved0", C.c_int32), ("traced_primary_rays", C.c_int64), ("culled_pixels", C.c_int64)]
 
     @property
     def total_rays(self):
         return self.primary_rays + self.shadow_rays + self.reflection_rays
+
+    @property
+    def walked_rays(self):
+        """Rays that walked the grid: total_rays minus the camera rays answered by the screen-tile cull."""
+        return self.traced_primary_rays + self.shadow_rays + self.reflection_rays
 
     def as_dict(self):
         arrays = ("hits_per_level", "trace_work", "shade_work", "wave_events", "wave_cycles", "level_trace_ms", "level_shade_ms")
@@ -73,6 +92,7 @@ class RenderStats(C.Structure):
         for k in arrays:
             d[k] = list(getattr(self, k))
         d["total_rays"] = self.total_rays
+        d["walked_rays"] = self.walked_rays
         return d
 
 
@@ -114,6 +134,8 @@ def _load():
         "rtx_render": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, C.POINTER(RenderStats)]),
         "rtx_render_device": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp,
                                         C.POINTER(RenderStats)]),
+        "rtx_frame_status": (C.c_int, [vp]),
+        "rtx_download_wave_log": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
         "rtx_intersect": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rtx_camera_rays": (C.c_int, [vp, C.POINTER(_Camera), i32, i32, i32, vp, vp]),
         "rtx_quantize": (C.c_int, [vp, C.c_int64, vp]),
@@ -132,7 +154,7 @@ EXPORTED_SYMBOLS = (
     "rtx_strerror", "rtx_last_error", "rtx_scene_load", "rtx_scene_parse", "rtx_scene_free", "rtx_scene_get_view",
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
-    "rtx_render_device", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
+    "rtx_render_device", "rtx_frame_status", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
     "rtx_save_image")
 
 
@@ -234,8 +256,17 @@ class SceneReader:
         return c
 
 
-def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags=0, workgroups_per_cu=0):
-    return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu)
+def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags=0, workgroups_per_cu=0, **sched):
+    """rtx_render_params from the call's arguments; scheduling / tuning keywords not given fall back to DEFAULTS."""
+    unknown = set(sched) - set(DEFAULTS)
+    if unknown:
+        raise TypeError(f"unknown render option(s): {sorted(unknown)}")
+    o = {k: (sched[k] if sched.get(k) is not None else v) for k, v in DEFAULTS.items()}
+    flags |= ((0 if o["tile_hint"] else RENDER_NO_TILE_HINT) | (0 if o["tile_cull"] else RENDER_NO_TILE_CULL) |
+              (0 if o["helpers"] else RENDER_NO_HELPERS) |
+              {0: 0, 3: RENDER_WAVES_3, 4: RENDER_WAVES_4}[int(o["frame_waves"])])
+    return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu,
+                         int(o["walk_budget"]), int(o["ready_threshold"]), int(o["drain_eighths"]), 0, int(o["round_limit"]))
 
 
 def local_rows(height, tile_rows=8, rank=0, world=1, width=1):
@@ -296,15 +327,17 @@ class Renderer:
         return start, ids[:n_refs]
 
     def render(self, width=0, height=0, max_depth=5, search=SEARCH_NESTED, tile_rows=8, rank=0, world=1,
-               want_ids=True, count_work=False, camera=None, eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False):
-        """Renders this rank's rows into full-size host arrays.  Returns (rgb[H,W,3], ids[H,W] or None, stats)."""
+               want_ids=True, count_work=False, camera=None, eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False,
+               **sched):
+        """Renders this rank's rows into full-size host arrays.  Returns (rgb[H,W,3], ids[H,W] or None, stats).
+        `sched`: scheduling / tuning keywords of DEFAULTS (tile_hint, tile_cull, helpers, frame_waves, ...)."""
         sc = self.scene
         W = width if width > 0 else sc.width
         H = height if height > 0 else sc.height
         cam = camera if camera is not None else sc._camera()
         flags = ((RENDER_COUNT_WORK if count_work else 0) | (RENDER_SERIAL_LANES if serial_lanes else 0) |
                  (RENDER_LEVEL_QUEUES if level_queues else 0))
-        p = _params(W, H, max_depth, eps_bias, search, tile_rows, rank, world, flags)
+        p = _params(W, H, max_depth, eps_bias, search, tile_rows, rank, world, flags, **sched)
         rgb = np.zeros((H, W, 3), np.float32)
         ids = np.full((H, W), -2, np.int32) if want_ids else None
         st = RenderStats()
@@ -313,18 +346,31 @@ class Renderer:
 
     def render_device(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8,
                       rank=0, world=1, stream=None, want_stats=False, count_work=False, camera=None,
-                      eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False, workgroups_per_cu=0):
+                      eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False, workgroups_per_cu=0, **sched):
         """Enqueues one frame writing DEVICE memory (raw pointers, e.g. torch tensor data_ptr())."""
         cam = camera if camera is not None else self.scene._camera()
         flags = ((RENDER_COUNT_WORK if count_work else 0) | (RENDER_SERIAL_LANES if serial_lanes else 0) |
                  (RENDER_LEVEL_QUEUES if level_queues else 0))
-        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu)
+        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu, **sched)
         st = RenderStats() if want_stats else None
         _check(_load().rtx_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_rgb_ptr),
                                          C.c_void_p(d_ids_ptr) if d_ids_ptr else None,
                                          C.c_void_p(stream) if stream else None,
                                          C.byref(st) if st is not None else None))
         return st
+
+    def frame_status(self):
+        """Waits for this context's last asynchronous frame; raises RtxError (RTX_E_LIMIT) if it was abandoned."""
+        _check(_load().rtx_frame_status(self._h))
+
+    def wave_log(self):
+        """[n_waves, 8] uint64 log of the last frame rendered with count_work (start, exhausted, end, rounds, updates,
+        pixels, deepest level, helper tasks per wave)."""
+        n = C.c_int64()
+        _check(_load().rtx_download_wave_log(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 8), np.uint64)
+        _check(_load().rtx_download_wave_log(self._h, _ptr(out), n.value, C.byref(n)))
+        return out[:n.value]
 
     def quantize_device(self, d_rgb_ptr, n_pixels, d_out_ptr, bgr=False, stream=None):
         """Enqueues the 8-bit conversion of a DEVICE float framebuffer into DEVICE bytes (raw pointers)."""

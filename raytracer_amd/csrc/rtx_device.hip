@@ -56,6 +56,10 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }      // a context's buffers go with the context (rtx_destroy makes its device current first)
     int reserve(size_t count) {
         if (count <= n && p) return RTX_OK;
         release();
@@ -119,6 +123,12 @@ struct rtx_ctx {
     DevBuf<int> ids_local;
     hipEvent_t ev[4 + 3 * 2 * RTX_MAX_LEVELS];
     bool have_events = false;
+    // Set by a wave of the frame kernel that ran into the round limit: one int of pinned host memory the kernel
+    // writes through its device address, so that an abandoned frame is noticed without a copy per frame.
+    int* abort_host = nullptr;
+    int* abort_dev = nullptr;
+    bool frame_pending = false;   // a frame kernel was enqueued and its status has not been looked at yet
+    size_t wave_log_waves = 0;    // waves logged by the last instrumented frame
 };
 
 namespace {
@@ -214,6 +224,36 @@ void screen_window(const DevCamera& cam, f3 lo, f3 hi, int W, int H, bool have_p
     *y0 = (int)std::max(0.0, std::min((double)H, std::floor(ymin - margin)));
     *x1 = (int)std::min((double)(W - 1), std::max(-1.0, std::ceil(xmax + margin)));
     *y1 = (int)std::min((double)(H - 1), std::max(-1.0, std::ceil(ymax + margin)));
+}
+
+// Rounds no wave of the frame kernel can exceed on a valid frame.  Every round of a wave moves at least one of its
+// unfinished rays one step along its walk (or tests the candidates of the cell it stands on, after which the next
+// round moves it), so a wave's rounds are bounded by the steps of all rays it can ever hold: every ray of the frame,
+// in the worst case.  A ray crosses at most rx + ry + rz coarse cells and, inside each, 3 * sub fine cells; each
+// crossing is at most two rounds (look, leave).
+long long derived_round_limit(const rtx_ctx* c, const DevFrame& f, int max_depth) {
+    const double rays_per_path = (double)(max_depth + 1) * (double)(c->n_lights + 1);
+    const DevGrid& g = c->dgrid;
+    const double steps_per_ray = 2.0 * (double)(g.rx + g.ry + g.rz + 3) * (double)(3 * std::max(g.sub, 1) + 2) + 8.0;
+    const double bound = ((double)f.n_items0 + 64.0) * rays_per_path * steps_per_ray;
+    return bound < 4.0e18 ? (long long)bound : (long long)4.0e18;
+}
+
+// Looks at the status word of the context's last frame; `wait` synchronises with the frame's end first.
+int take_frame_status(rtx_ctx* c, bool wait) {
+    if (!c->frame_pending) return RTX_OK;
+    if (wait) {
+        if (hipEventSynchronize(c->ev[2]) != hipSuccess) { rtx_set_error("waiting for the last frame failed"); return RTX_E_DEVICE; }
+    } else if (hipEventQuery(c->ev[2]) != hipSuccess) {
+        return RTX_OK;            // still running: whoever looks next finds it
+    }
+    c->frame_pending = false;
+    if (*(volatile int*)c->abort_host != 0) {
+        *c->abort_host = 0;
+        rtx_set_error("frame abandoned: a wave of the frame kernel reached the round limit; the image is incomplete");
+        return RTX_E_LIMIT;
+    }
+    return RTX_OK;
 }
 
 int ensure_workspace(rtx_ctx* c, size_t pixels, int levels) {
@@ -329,6 +369,13 @@ int rtx_create(rtx_ctx** out, int device_id) {
         if (hipEventCreate(&ev) != hipSuccess) { delete c; rtx_set_error("hipEventCreate failed"); return RTX_E_DEVICE; }
     }
     c->have_events = true;
+    if (hipHostMalloc((void**)&c->abort_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&c->abort_dev, c->abort_host, 0) != hipSuccess) {
+        rtx_set_error("rtx_create: pinned status word could not be allocated");
+        rtx_destroy(c);
+        return RTX_E_NOMEM;
+    }
+    *c->abort_host = 0;
     *out = c;
     return RTX_OK;
 }
@@ -339,18 +386,8 @@ void rtx_destroy(rtx_ctx* c) {
     (void)hipDeviceSynchronize();
     if (c->have_events)
         for (auto& ev : c->ev) (void)hipEventDestroy(ev);
-    c->prims.release(); c->tri_normal.release(); c->xinv.release(); c->xfwd.release(); c->mats.release();
-    c->lights.release(); c->geom.release(); c->kind.release(); c->xform.release();
-    c->ref_box.release(); c->tight_box.release(); c->bounds.release();
-    c->cstart.release(); c->cids.release(); c->fstart.release(); c->fids.release(); c->scratch_ids.release();
-    c->cell_tmp.release(); c->cocc.release();
-    c->wmask.release(); c->cocc_bits.release(); c->wpop.release(); c->wpre.release(); c->ostart.release(); c->words.release();
-    c->counters.release(); c->work.release(); c->hP.release(); c->hN.release(); c->hD.release(); c->pix0.release();
-    for (int k = 0; k < 2; k++) { c->rO[k].release(); c->rD[k].release(); }
-    for (int l = 0; l < RTX_MAX_LEVELS; l++) { c->hL[l].release(); c->hChild[l].release(); }
-    c->path_stack.release();
-    c->rgb_local.release(); c->ids_local.release();
-    delete c;
+    if (c->abort_host) (void)hipHostFree(c->abort_host);
+    delete c;                     // every DevBuf releases its memory
 }
 
 int rtx_set_scene(rtx_ctx* c, const rtx_scene_view* v) {
@@ -653,6 +690,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     DeviceGuard guard(c->device);
     if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
     hipStream_t st = (hipStream_t)stream;
+    if ((rc = take_frame_status(c, false))) return rc;      // an earlier asynchronous frame that was abandoned
 
     const int nl = count_local_rows(p->height, tile_rows, rank, world);
     const int levels = p->max_depth + 1;
@@ -661,7 +699,6 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
-    if (const char* e = getenv("RTX_BLOCKS_PER_CU")) blocks = c->n_cus * std::max(1, atoi(e));   // tuning knob
     if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
     } else {
@@ -709,9 +746,10 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     // in flight) gains no residency from the smaller budget.
     const double pixels_per_lane = (double)f.n_items0 / ((double)blocks * RTX_BLOCK);
     int frame_waves = pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_4_WAVES && blocks >= 2 * c->n_cus ? 4 : 3;
-    if (const char* e = getenv("RTX_FRAME_WAVES")) frame_waves = atoi(e);                       // A/B knob
+    if (p->flags & RTX_RENDER_WAVES_3) frame_waves = 3;
+    if (p->flags & RTX_RENDER_WAVES_4) frame_waves = 4;
     bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
-    if (const char* e = getenv("RTX_TILE_CULL")) tile_cull = tile_cull && atoi(e) != 0;          // A/B knob
+    if (p->flags & RTX_RENDER_NO_TILE_CULL) tile_cull = false;
     if (tile_cull) {
         const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
         // + 16 bytes: the clear kernel writes whole 16-byte words
@@ -725,14 +763,12 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     }
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
-    f.walk_budget = 3;
-    f.ready_threshold = 48;
-    f.drain_num = 2;
-    f.helpers = 1;
-    if (const char* e = getenv("RTX_HELPERS")) f.helpers = atoi(e) != 0;
-    if (const char* e = getenv("RTX_DRAIN_NUM")) f.drain_num = std::max(0, atoi(e));
-    if (const char* e = getenv("RTX_WALK_BUDGET")) f.walk_budget = std::max(1, atoi(e));          // tuning knobs
-    if (const char* e = getenv("RTX_READY_THRESHOLD")) f.ready_threshold = std::max(1, atoi(e));
+    f.walk_budget = p->walk_budget > 0 ? p->walk_budget : 3;
+    f.ready_threshold = p->ready_threshold > 0 ? std::min(p->ready_threshold, 64) : 48;
+    f.drain_num = p->drain_eighths > 0 ? std::min(p->drain_eighths, 8) : 2;
+    f.helpers = (p->flags & RTX_RENDER_NO_HELPERS) ? 0 : 1;
+    f.round_limit = p->round_limit > 0 ? (long long)p->round_limit : derived_round_limit(c, f, p->max_depth);
+    f.abort_host = c->abort_dev;
     f.rgb = d_rgb;
     f.ids = d_ids;
     f.counters = c->counters.p;
@@ -783,13 +819,11 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         // the previous frame's per-block path depths order this frame's list if they were recorded for the same
         // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
         const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
-        bool feedback = c->cost_valid && memcmp(key, c->cost_key, sizeof key) == 0;
-        if (const char* e = getenv("RTX_TILE_FEEDBACK")) feedback = feedback && atoi(e) != 0;     // A/B knob
+        const bool feedback = c->cost_valid && memcmp(key, c->cost_key, sizeof key) == 0 && !(p->flags & RTX_RENDER_NO_TILE_HINT);
         const int* prev_cost = feedback ? c->tile_cost[c->cost_cur ^ 1].p : nullptr;
         // a tile takes the deepest class recorded within hint_radius tiles around it: one tile allows for a camera
         // that moved a little; the very same camera needs no allowance (4K frame of scene7: 2.08 against 2.19 ms)
         f.hint_radius = feedback && memcmp(cam, &c->cost_cam, sizeof *cam) == 0 ? 0 : 1;
-        if (const char* e = getenv("RTX_HINT_RADIUS")) f.hint_radius = std::max(0, std::min(16, atoi(e)));
         c->cost_cam = *cam;
         f.tile_cost = c->tile_cost[c->cost_cur].p;
         memcpy(c->cost_key, key, sizeof key);
@@ -825,13 +859,18 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     }
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipGetLastError());
+    c->frame_pending = !level_queues;
 
     if (stats) {
+        if ((rc = take_frame_status(c, true))) return rc;
         HIP_TRY(hipEventSynchronize(ev[2]));
         int cnt[CNT_TOTAL];
         HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         stats->primary_rays = (int64_t)pixels;
+        // the level-synchronous pipelines walk every pixel's camera ray
+        stats->traced_primary_rays = level_queues ? (int64_t)pixels : (int64_t)cnt[CNT_PIXELS];
+        stats->culled_pixels = stats->primary_rays - stats->traced_primary_rays;
         for (int l = 0; l < levels; l++) {
             stats->hits_per_level[l] = cnt[CNT_HITS + l];
             stats->shadow_rays += (int64_t)cnt[CNT_HITS + l] * c->n_lights;
@@ -854,23 +893,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
             stats->trace_launches = 1;                 // the persistent frame kernel does everything
             (void)hipEventElapsedTime(&stats->trace_ms, ev[3], ev[1]);
         }
-        if (count && !level_queues) {
-            // development aid: per-wave log of the instrumented frame kernel as CSV
-            if (const char* path = getenv("RTX_WAVE_LOG")) {
-                const size_t n_waves = (size_t)blocks * (RTX_BLOCK / 64);
-                std::vector<unsigned long long> log(8 * n_waves);
-                HIP_TRY(hipMemcpy(log.data(), c->work.p + 24, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                if (FILE* fh = fopen(path, "w")) {
-                    fprintf(fh, "wave,start,exhausted,end,rounds,updates,pixels,deepest,helper_tasks\n");
-                    for (size_t k = 0; k < n_waves; k++) {
-                        fprintf(fh, "%zu", k);
-                        for (int j = 0; j < 8; j++) fprintf(fh, ",%llu", log[8 * k + j]);
-                        fprintf(fh, "\n");
-                    }
-                    fclose(fh);
-                }
-            }
-        }
+        if (count && !level_queues) c->wave_log_waves = (size_t)blocks * (RTX_BLOCK / 64);
         if (count) {
             unsigned long long w[24];
             HIP_TRY(hipMemcpy(w, c->work.p, sizeof w, hipMemcpyDeviceToHost));
@@ -918,6 +941,27 @@ int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, fl
     for (int r = 0; r < nl; r++) {
         memcpy(rgb_out + (size_t)rows[r] * W * 3, rgb.data() + (size_t)r * W * 3, W * 3 * sizeof(float));
         if (prim_id_out) memcpy(prim_id_out + (size_t)rows[r] * W, ids.data() + (size_t)r * W, W * sizeof(int32_t));
+    }
+    return RTX_OK;
+}
+
+int rtx_frame_status(rtx_ctx* c) {
+    if (!c) { rtx_set_error("rtx_frame_status: null context"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    return take_frame_status(c, true);
+}
+
+int rtx_download_wave_log(rtx_ctx* c, uint64_t* out, int64_t max_waves, int64_t* n_waves) {
+    if (!c || !n_waves || max_waves < 0 || (max_waves > 0 && !out)) { rtx_set_error("rtx_download_wave_log: bad argument"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    const size_t n = std::min<size_t>(c->wave_log_waves, (size_t)max_waves);
+    *n_waves = (int64_t)c->wave_log_waves;
+    if (n > 0) {
+        if (c->work.n < 24 + 8 * c->wave_log_waves) { rtx_set_error("rtx_download_wave_log: no log held"); return RTX_E_STATE; }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, c->work.p + 24, 8 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     return RTX_OK;
 }

@@ -19,6 +19,8 @@ struct DevCamera {
 #define CNT_TILES 64        // 8x8 pixel tiles the frame kernel traces (tile list)
 #define CNT_TILES_ALL 65    // set when a fine cell's screen footprint was too large or undefined: every tile is traced
 #define CNT_CLASS 66        // 8 counters: tiles per scheduling class; 74..81: fill cursors per class
+#define CNT_ABORT 82        // set by a wave of the frame kernel that reached the round limit
+#define CNT_PIXELS 83       // pixels whose camera ray the frame kernel walked
 #define CNT_TOTAL 96
 
 struct DevFrame {
@@ -41,6 +43,8 @@ struct DevFrame {
     int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
     int drain_num;                 // ... after the cursor is exhausted: that many eighths of the lanes still alive
     int helpers;                   // persistent kernel: idle lanes of a draining wave trace the shadow rays of fresh hits
+    long long round_limit;         // persistent kernel: rounds after which a wave abandons the frame
+    int* abort_host;               // ... and says so here (device address of a word of pinned host memory)
     DevCamera cam;
     float* rgb;                    // [n_local_rows][W][3]
     int* ids;                      // [n_local_rows][W] or null

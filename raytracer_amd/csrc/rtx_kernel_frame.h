@@ -64,7 +64,8 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     // term into the path's slot; a path folds only when all its helpers have reported (pending_helpers).
     const bool helpers = f.helpers != 0;
     outstanding[wave][lane] = 0;
-    int guard = 0;                                      // bounds the loop whatever happens: a frame needs a few thousand rounds
+    long long rounds_left = f.round_limit;              // bounds the loop whatever happens (the host derives it from the frame)
+    int n_drawn = 0;                                    // pixels this lane drew
     // instrumented build: when the wave started, ran out of new pixels and ended (100 MHz clock), what it did
     unsigned long long log_start = 0, log_exhausted = 0;
     int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0, log_tasks = 0;
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                             const int tile = lr / f.tile_rows;
                             const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
                             pix = lr * f.W + x;
+                            n_drawn++;
                             if (COUNT) log_pixels++;
                             O = f.cam.eye;
                             rayDir = camera_ray(f.cam, x, y);
@@ -280,9 +282,15 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
         }
         if (COUNT) log_rounds++;
         if (__any(pix != -1 && w.state != 2)) wave_round<MODE, SINGLE_XF, COUNT, PRIMS, (WAVES < 4)>(sc, g, sp, occ, xf, l, w, r, phase != 0, f.walk_budget, wc);
-        if (++guard > (1 << 22)) break;
+        if (--rounds_left < 0) {
+            // the frame is abandoned: pixels still in flight keep the fill colour, and the host is told
+            if (lane == 0) { f.counters[CNT_ABORT] = 1; *f.abort_host = 1; }
+            break;
+        }
     }
     if (lane < RTX_MAX_LEVELS && hit_count[wave][lane]) atomicAdd(f.counters + CNT_HITS + lane, hit_count[wave][lane]);
+    for (int off = 32; off > 0; off >>= 1) n_drawn += __shfl_down(n_drawn, off);
+    if (lane == 0 && n_drawn) atomicAdd(f.counters + CNT_PIXELS, n_drawn);
     if (COUNT) {
         flush_work(wc, f.work);
         int pixels = log_pixels, deepest = log_deepest, tasks = log_tasks;

@@ -8,6 +8,7 @@
 #include "rt_xform.h"
 #include "rtx_internal.h"
 
+#include <algorithm>
 #include <cerrno>
 #include <charconv>
 #include <cstdio>
@@ -48,46 +49,91 @@ inline bool next_token(Cursor& c, const char*& tok, size_t& len) {
     len = (size_t)(c.p - tok);
     return len > 0;
 }
-// formatted-extraction semantics of `stream >> float`: a missing or malformed field reads as 0 and
-// poisons the rest of the line (every later field of that line reads 0 as well)
+// Formatted-extraction semantics of `linestream >> a >> b >> c` (src/readScene.h:70-170) for one line:
+//   * a field that parses is stored;
+//   * a field that is present but malformed stores 0 and fails the stream (C++11 num_get);
+//   * a field that is missing stores nothing and fails the stream (the sentry fails at end of line);
+//   * once the stream has failed, every later extraction stores nothing.
+// A number followed by junk ("1.5abc") stores the number and leaves the junk in the stream, where the next
+// extraction finds it malformed.  The state directives (ambient, diffuse, ..., camera, size) extract straight into
+// the state, so a short or malformed line keeps the earlier values of the fields it does not reach; directives that
+// extract into locals (vertex, tri, sphere, translate, ...) read indeterminate values there, for which this parser
+// takes 0.
 struct Fields {
     Cursor c;
     bool failed = false;
-    // Decimal -> float, correctly rounded as the stream extraction is.  std::from_chars covers the plain
-    // decimal spellings scene files use; anything it does not take whole (a leading '+', a hexadecimal
-    // float, trailing characters) goes through strtof, whose prefix rule is the one the parser had before.
-    float f() {
+    // The prefix of a token that the stream accumulates for a floating-point field before converting it:
+    // [sign] digits [. digits] [e|E [sign] digits]  (any part may be empty; the conversion then rejects it).
+    static size_t number_prefix(const char* t, size_t n) {
+        size_t m = 0;
+        if (m < n && (t[m] == '+' || t[m] == '-')) m++;
+        while (m < n && t[m] >= '0' && t[m] <= '9') m++;
+        if (m < n && t[m] == '.') { m++; while (m < n && t[m] >= '0' && t[m] <= '9') m++; }
+        if (m < n && (t[m] == 'e' || t[m] == 'E')) {
+            m++;
+            if (m < n && (t[m] == '+' || t[m] == '-')) m++;
+            while (m < n && t[m] >= '0' && t[m] <= '9') m++;
+        }
+        return m;
+    }
+    bool begin(const char*& t, size_t& n) {
+        if (failed) return false;
+        if (!next_token(c, t, n)) { failed = true; return false; }   // missing: nothing is stored
+        return true;
+    }
+    // Decimal -> float, correctly rounded as the stream extraction is.  std::from_chars covers the plain decimal
+    // spellings scene files use; anything it does not take whole (a leading '+', trailing characters) goes through
+    // strtof on the prefix the stream would have accumulated.
+    bool f(float& dst) {
         const char* t;
         size_t n;
-        if (failed || !next_token(c, t, n)) { failed = true; return 0.0f; }
+        if (!begin(t, n)) return false;
         float v = 0.0f;
         const std::from_chars_result r = std::from_chars(t, t + n, v);
-        if (r.ec == std::errc() && r.ptr == t + n) return v;
-        char buf[64];
-        if (n >= sizeof buf) { failed = true; return 0.0f; }
-        memcpy(buf, t, n);
-        buf[n] = 0;
-        char* e = nullptr;
-        v = strtof(buf, &e);
-        if (e == buf) { failed = true; return 0.0f; }
-        return v;
+        if (r.ec == std::errc() && r.ptr == t + n && number_prefix(t, n) == n) { dst = v; return true; }
+        const size_t m = std::min(number_prefix(t, n), (size_t)63);
+        if (m > 0) {
+            char buf[64];
+            memcpy(buf, t, m);
+            buf[m] = 0;
+            char* e = nullptr;
+            v = strtof(buf, &e);
+            if (e == buf + m) {                                         // the accumulated characters are a number
+                dst = v;
+                c.p = t + m;                                            // the rest of the token stays in the stream
+                return true;
+            }
+        }
+        dst = 0.0f;                                                     // malformed
+        failed = true;
+        return false;
     }
-    long i() {
+    bool i(long& dst) {
         const char* t;
         size_t n;
-        if (failed || !next_token(c, t, n)) { failed = true; return 0; }
+        if (!begin(t, n)) return false;
         long v = 0;
         const std::from_chars_result r = std::from_chars(t, t + n, v, 10);
-        if (r.ec == std::errc() && r.ptr == t + n) return v;
+        if (r.ec == std::errc() && r.ptr == t + n) { dst = v; return true; }
         char buf[64];
-        if (n >= sizeof buf) { failed = true; return 0; }
-        memcpy(buf, t, n);
-        buf[n] = 0;
+        size_t m = 0;
+        if (m < n && (t[m] == '+' || t[m] == '-')) buf[m] = t[m], m++;
+        while (m < n && m + 1 < sizeof buf && t[m] >= '0' && t[m] <= '9') { buf[m] = t[m]; m++; }
+        buf[m] = 0;
         char* e = nullptr;
         v = strtol(buf, &e, 10);
-        if (e == buf) { failed = true; return 0; }
-        return v;
+        if (m > 0 && e == buf + m) {
+            dst = v;
+            c.p = t + m;
+            return true;
+        }
+        dst = 0;
+        failed = true;
+        return false;
     }
+    // extraction into a local that starts at 0
+    float f() { float v = 0.0f; f(v); return v; }
+    long i() { long v = 0; i(v); return v; }
 };
 
 struct MatKey {
@@ -183,13 +229,14 @@ int parse_text(const char* text, size_t n_bytes, rtx_scene* sc) {
             sc->prim_material.push_back(cur_material());
             sc->prim_xform.push_back(cur_xform());
         } else if (cmd_is(t, n, "size")) {
-            sc->width = (int32_t)fl.i();
-            sc->height = (int32_t)fl.i();
+            long w = sc->width, h = sc->height;
+            fl.i(w); fl.i(h);
+            sc->width = (int32_t)w; sc->height = (int32_t)h;
         } else if (cmd_is(t, n, "camera")) {
-            for (int k = 0; k < 3; k++) sc->cam.eye[k] = fl.f();
-            for (int k = 0; k < 3; k++) sc->cam.center[k] = fl.f();
-            for (int k = 0; k < 3; k++) sc->cam.up[k] = fl.f();
-            sc->cam.fov_deg = fl.f();
+            for (int k = 0; k < 3; k++) fl.f(sc->cam.eye[k]);
+            for (int k = 0; k < 3; k++) fl.f(sc->cam.center[k]);
+            for (int k = 0; k < 3; k++) fl.f(sc->cam.up[k]);
+            fl.f(sc->cam.fov_deg);
         } else if (cmd_is(t, n, "point") || cmd_is(t, n, "directional")) {
             const bool point = cmd_is(t, n, "point");
             float l[10];
@@ -201,12 +248,12 @@ int parse_text(const char* text, size_t n_bytes, rtx_scene* sc) {
             l[8] = point ? atten[1] : 0.0f;
             l[9] = point ? atten[2] : 0.0f;
             sc->lights.insert(sc->lights.end(), l, l + 10);
-        } else if (cmd_is(t, n, "ambient")) { for (int k = 0; k < 3; k++) ambient[k] = fl.f(); material_id = -1; }
-        else if (cmd_is(t, n, "diffuse")) { for (int k = 0; k < 3; k++) diffuse[k] = fl.f(); material_id = -1; }
-        else if (cmd_is(t, n, "specular")) { for (int k = 0; k < 3; k++) specular[k] = fl.f(); material_id = -1; }
-        else if (cmd_is(t, n, "emission")) { for (int k = 0; k < 3; k++) emission[k] = fl.f(); material_id = -1; }
-        else if (cmd_is(t, n, "shininess")) { shininess = fl.f(); material_id = -1; }
-        else if (cmd_is(t, n, "attenuation")) { for (int k = 0; k < 3; k++) atten[k] = fl.f(); }
+        } else if (cmd_is(t, n, "ambient")) { for (int k = 0; k < 3; k++) fl.f(ambient[k]); material_id = -1; }
+        else if (cmd_is(t, n, "diffuse")) { for (int k = 0; k < 3; k++) fl.f(diffuse[k]); material_id = -1; }
+        else if (cmd_is(t, n, "specular")) { for (int k = 0; k < 3; k++) fl.f(specular[k]); material_id = -1; }
+        else if (cmd_is(t, n, "emission")) { for (int k = 0; k < 3; k++) fl.f(emission[k]); material_id = -1; }
+        else if (cmd_is(t, n, "shininess")) { fl.f(shininess); material_id = -1; }
+        else if (cmd_is(t, n, "attenuation")) { for (int k = 0; k < 3; k++) fl.f(atten[k]); }
         else if (cmd_is(t, n, "pushTransform")) { stack.push_back(stack.back()); }
         else if (cmd_is(t, n, "popTransform")) { if (stack.size() > 1) stack.pop_back(); xform_id = -1; }   // identity is unpoppable
         else if (cmd_is(t, n, "translate")) {

@@ -61,6 +61,11 @@ def test_render_matches_golden(renderer, name, mode, pipeline):
     cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
     assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
     assert st.light_evals == cnt["light_evals"]
+    # camera rays answered by a fill instead of a walk are reported, and only ones that hit nothing can be among them
+    assert st.traced_primary_rays + st.culled_pixels == st.primary_rays
+    assert st.culled_pixels <= int((g["ids"] < 0).sum()) and st.walked_rays == st.total_rays - st.culled_pixels
+    if pipeline != "frame":
+        assert st.culled_pixels == 0
     if pipeline == "frame" and mode == rt.SEARCH_NESTED:
         # camera rays through screen tiles that see no occupied fine cell are answered without walking the grid
         assert 0 < st.cell_steps <= cnt["cell_steps"]
@@ -111,6 +116,101 @@ def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
     rows = np.arange(1000, H, 160)
     assert_image_parity(rgb_n[rows], ids_n[rows], rgb_ref[rows], ids_ref[rows])
     assert (ids_ref[rows] >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("sub", [6, 12])
+def test_scene7_4k_whole_frame_matches_the_oracle_golden(renderer, sub):
+    """The benchmark's frame (scene7 @ 3840x2160, depth 5), every one of its 8.3 M pixels against the committed oracle
+    frame (tests/golden/make_golden_4k.py): at the benchmark's own grid setting (sub 6) and at a finer one, without and
+    with the previous frame's scheduling hint, both builds of the frame kernel."""
+    import hashlib
+    g = np.load(os.path.join(GOLDEN, "golden_scene7_4k.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    load(renderer, "scene7", sub)
+    for kw in (dict(tile_hint=False), dict(), dict(frame_waves=3), dict(tile_cull=False, helpers=False)):
+        rgb, ids, st = renderer.render(W, H, int(g["max_depth"]), rt.SEARCH_NESTED, **kw)
+        assert np.array_equal(ids, g["ids"]), f"{int((ids != g['ids']).sum())} primary hit ids differ ({kw})"
+        d = np.abs(rt.quantize(rgb).astype(np.int16) - g["rgb8"].astype(np.int16)).max(axis=2)
+        assert (d > 1).sum() == 0 and (d > 0).mean() <= 1e-3, kw
+        # the float framebuffer itself: identical up to the last bit of pow() (device fp64 evaluation, host powf)
+        same_bits = hashlib.sha256(rgb.tobytes()).hexdigest() == str(g["rgb_sha256"])
+        assert same_bits or np.abs(rgb.astype(np.float64).sum(axis=(1, 2)) - g["rgb_row_sums"]).max() <= FLOAT_TOL * 3 * W
+        assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+        assert st.culled_pixels <= int((g["ids"] < 0).sum())
+
+
+def _camera_from_line(line):
+    v = [float(x) for x in line.split()[1:11]]
+    cam = rt.api._Camera()
+    for k in range(3):
+        cam.eye[k], cam.center[k], cam.up[k] = v[k], v[3 + k], v[6 + k]
+    cam.fov_deg = v[9]
+    return cam
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene2"])
+def test_resident_scene_rendered_under_every_camera_of_its_file(renderer, tmp_path, name):
+    """The scene and its grid are uploaded and built once; each of the cameras the scene file lists (res/scene1.test:9-12,
+    res/scene2.test:17-19) is then only an argument of the render call.  Every frame against the oracle's render of the
+    file with that camera line active; twice round, so that each camera also runs with another camera's scheduling hint."""
+    from test_oracle_fixtures import _with_camera
+    lines = [l.lstrip("#") for l in open(scene_path(name)).read().splitlines() if l.lstrip("#").startswith("camera ")]
+    assert len(lines) == (4 if name == "scene1" else 3)
+    want = []
+    for which in range(1, len(lines) + 1):
+        rgb_ref, ids_ref, _, cnt = RefScene(_with_camera(tmp_path, name, which), counting=True).render(0, 0, 5)
+        want.append((rgb_ref, ids_ref, cnt))
+    assert len({w[1].tobytes() for w in want}) == len(lines)           # the cameras do see different frames
+    load(renderer, name)                                               # the file's active camera is not used below
+    for _ in range(2):
+        for line, (rgb_ref, ids_ref, cnt) in zip(lines, want):
+            for mode in MODES:
+                rgb, ids, st = renderer.render(0, 0, 5, mode, camera=_camera_from_line(line))
+                assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+                assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
+def test_contexts_give_their_device_memory_back():
+    """Create, upload, build, render, destroy -- five times over: free device memory returns to where it was after the
+    first cycle (scene7's nested grid alone is 18 MB of records per context)."""
+    sr = rt.SceneReader().readScene(scene_path("scene7"))
+
+    def cycle():
+        r = rt.Renderer(0)
+        r.set_scene(sr)
+        r.build_grid(15, 6)
+        r.render(320, 180, 5)
+        r.render(320, 180, 5, level_queues=True)
+        r.close()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    first = cycle()
+    free = [cycle() for _ in range(5)]
+    assert min(free) >= first - (4 << 20), f"free memory fell from {first} to {min(free)} bytes over five contexts"
+
+
+def test_round_limit_abandons_the_frame_with_an_error(renderer):
+    """A wave of the frame kernel that reaches the round limit gives the frame up; the caller gets RTX_E_LIMIT, not an
+    image with holes and RTX_OK.  The default limit is derived from the frame and is never reached by a valid one."""
+    load(renderer, "scene6")
+    with pytest.raises(rt.RtxError) as e:
+        renderer.render(160, 120, 5, round_limit=3)
+    assert e.value.code == -6 and "round limit" in str(e.value)
+    d_rgb = torch.zeros((120, 160, 3), dtype=torch.float32, device="cuda")
+    renderer.render_device(d_rgb.data_ptr(), 0, 160, 120, 5, round_limit=3)        # asynchronous: no status yet
+    with pytest.raises(rt.RtxError) as e:
+        renderer.frame_status()
+    assert e.value.code == -6
+    renderer.frame_status()                                                        # reported once
+    renderer.render_device(d_rgb.data_ptr(), 0, 160, 120, 5, round_limit=3)
+    torch.cuda.synchronize()
+    with pytest.raises(rt.RtxError):                                               # the next call on the context reports it
+        renderer.render_device(d_rgb.data_ptr(), 0, 160, 120, 5)
+    rgb_ref, ids_ref, _, _ = RefScene(scene_path("scene6")).render(160, 120, 5)
+    rgb, ids, _ = renderer.render(160, 120, 5, round_limit=0)                      # derived limit: the whole frame
+    assert_image_parity(rgb, ids, rgb_ref, ids_ref)
 
 
 @pytest.mark.parametrize("depth", [0, 1, 3, 8, 15])
@@ -462,7 +562,7 @@ def test_schedule_hints_never_change_the_frame(renderer):
 
 
 @pytest.mark.parametrize("name,sub", [("scene4-specular", 0), ("scene5", 0), ("scene6", 0), ("scene7", 6)])
-def test_both_register_budgets_of_the_frame_kernel(renderer, monkeypatch, name, sub):
+def test_both_register_budgets_of_the_frame_kernel(renderer, name, sub):
     """The frame kernel is compiled for three and for four resident waves per SIMD (168 / 128 registers, six / five
     path levels in LDS, deeper ones in global memory) and the library picks one by the size of the frame.  Forced
     either way, at a depth inside the LDS levels and at one beyond them, with and without helpers: the frame equals the
@@ -471,12 +571,10 @@ def test_both_register_budgets_of_the_frame_kernel(renderer, monkeypatch, name, 
     W, H = 320, 240
     for depth in (5, 9):
         want_rgb, want_ids, _ = renderer.render(W, H, depth, level_queues=True)
-        for waves in ("3", "4"):
-            for helpers in ("1", "0"):
-                monkeypatch.setenv("RTX_FRAME_WAVES", waves)
-                monkeypatch.setenv("RTX_HELPERS", helpers)
+        for waves in (3, 4):
+            for helpers in (True, False):
                 for _ in range(2):                     # second frame: ordered by the first one's path depths
-                    rgb, ids, _ = renderer.render(W, H, depth)
+                    rgb, ids, _ = renderer.render(W, H, depth, frame_waves=waves, helpers=helpers)
                     assert np.array_equal(ids, want_ids), (depth, waves, helpers)
                     assert np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)), (depth, waves, helpers)
 
@@ -560,9 +658,9 @@ def _random_scene(rng, n_tris, n_spheres, n_lights):
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_random_scenes_match_the_oracle(renderer, tmp_path, monkeypatch, seed):
+def test_random_scenes_match_the_oracle(renderer, tmp_path, seed):
     # frames this small would all run the frame kernel's three-wave build: odd seeds force the four-wave one
-    monkeypatch.setenv("RTX_FRAME_WAVES", "4" if seed % 2 else "3")
+    waves = 4 if seed % 2 else 3
     rng = np.random.default_rng(1000 + seed)
     text = _random_scene(rng, int(rng.integers(0, 120)), int(rng.integers(0, 30)), int(rng.integers(0, 4)))
     path = tmp_path / "random.test"
@@ -574,9 +672,10 @@ def test_random_scenes_match_the_oracle(renderer, tmp_path, monkeypatch, seed):
     for mode in MODES:
         for kw in PIPELINES.values():
             for _ in range(2):                       # the second frame runs with the first one's scheduling hint
-                rgb, ids, st = renderer.render(0, 0, depth, mode, **kw)
+                rgb, ids, st = renderer.render(0, 0, depth, mode, frame_waves=waves, **kw)
                 assert_image_parity(rgb, ids, rgb_ref, ids_ref)
                 assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+                assert st.traced_primary_rays + st.culled_pixels == st.primary_rays and st.traced_primary_rays >= int((ids_ref >= 0).sum())
 
 
 def test_bench_line_has_the_contracted_fields():

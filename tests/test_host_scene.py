@@ -71,6 +71,60 @@ def test_missing_fields_read_as_zero_and_poison_the_line():
     assert list(sr.prim_geom[0]) == [1, 2, 0, 1, 0, 0, 0, 1, 0]
 
 
+SHORT_LINE_SCENE = """size 640 480
+size 320
+camera 1 2 3 4 5 6 0 1 0 45
+camera 9 8
+ambient .1 .2 .3
+ambient .7
+diffuse .5 .6 .7
+diffuse x .9 .9
+specular .2 .3 .4
+specular .8 oops .9
+emission .01 .02 .03
+emission
+shininess 12
+shininess
+attenuation 1 .5 .25
+attenuation 2
+point 1 2 3 1 1 1
+attenuation 3 .1abc .7
+point 4 5 6 1 1 1
+vertex 0 0 0
+vertex 1 0 0
+vertex 0 1 0
+tri 0 1 2
+shininess 1.5e
+diffuse 1e1 +2 3.
+tri 0 1 2
+ambient .25.5 7
+tri 0 1 2
+"""
+
+
+def test_short_and_malformed_state_lines_keep_what_the_stream_keeps(tmp_path):
+    """`linestream >> a >> b >> c` (src/readScene.h:70-170): a missing field and every field after a failure leave their
+    targets as they were, the first malformed field reads 0, a number followed by junk leaves the junk for the next
+    field.  No scene the reference ships has such lines; the oracle parses with the same stream calls."""
+    path = tmp_path / "short.test"
+    path.write_text(SHORT_LINE_SCENE)
+    ref = RefScene(str(path))
+    sr = rt.SceneReader().readScene(str(path))
+    cam = ref.camera()
+    assert (sr.width, sr.height) == (ref.width, ref.height) == (320, 480)
+    for k in ("eye", "center", "up"):
+        assert np.array_equal(bits(sr.camera[k]), bits(cam[k]))
+    assert list(sr.camera["eye"]) == [9, 8, 3] and sr.camera["fov"] == cam["fov"] == 45
+    assert np.array_equal(bits(sr.materials[sr.prim_material]), bits(ref.prims()["mat"]))
+    assert np.array_equal(bits(sr.lights), bits(ref.lights()))
+    m = sr.materials[sr.prim_material]
+    f = np.float32
+    assert list(m[0]) == [f(.7), f(.2), f(.3), 0, f(.6), f(.7), f(.8), 0, f(.4), f(.01), f(.02), f(.03), 12]
+    assert m[1][12] == 0 and list(m[1][3:6]) == [10, 2, 3]           # "1.5e" is malformed: 0
+    assert list(m[2][0:3]) == [f(.25), f(.5), 7]                      # ".25.5" is two numbers: .25 and .5
+    assert [list(l[7:]) for l in sr.lights] == [[2, f(.5), f(.25)], [3, f(.1), 0]]      # "abc" is what the third field finds: 0
+
+
 def test_errors_are_codes_not_crashes(tmp_path):
     with pytest.raises(rt.RtxError) as e:
         rt.SceneReader().readScene(str(tmp_path / "nope.test"))

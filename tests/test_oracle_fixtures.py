@@ -28,22 +28,38 @@ def _with_camera(tmp_path, name, which):
     return str(path)
 
 
-# camera 3 of scene1 sees the quad at a grazing angle: a sliver whose JPEG edge weighs more in the overlap measure
-@pytest.mark.parametrize("name,which,jpg,min_iou", [
-    ("scene1", 1, "scene1-camera1.jpg", 0.97), ("scene1", 2, "scene1-camera2.jpg", 0.97), ("scene1", 3, "scene1-camera3.jpg", 0.96),
-    ("scene1", 4, "scene1-camera4.jpg", 0.97), ("scene2", 1, "scene2-camera1.jpg", 0.97), ("scene2", 2, "scene2-camera2.jpg", 0.97),
-    ("scene2", 3, "scene2-camera3.jpg", 0.97), ("scene3", 1, "scene3.jpg", 0.97)])
-def test_oracle_matches_course_render(tmp_path, name, which, jpg, min_iou):
+# Measured agreement of the oracle with each course JPEG (lossy, rendered by the course's own renderer), printed by this
+# test with -s: mean absolute error in 8-bit steps over the whole image, overlap (IoU) of the silhouettes, and the
+# largest difference of the mean colour over the interior of the common silhouette (eroded by four pixels, away from
+# the JPEG's ringing at edges):
+#   scene1 camera1 0.503 0.9912 0.37   camera2 0.574 0.9873 0.38   camera3 0.258 0.9664 0.12   camera4 0.302 0.9751 0.34
+#   scene2 camera1 1.004 0.9857 0.53   camera2 1.001 0.9897 0.47   camera3 1.077 0.9889 0.30   scene3 1.253 0.9837 1.17
+# The bounds below are those figures plus a small margin.  scene1 is the only shaded fixture (a quad lit by a point and
+# a directional light, diffuse only): its interior mean colour pins the Lambert term and both light kinds to within
+# half an 8-bit step; scenes 2 and 3 are ambient-only and pin camera, transform stack and both primitive tests.
+@pytest.mark.parametrize("name,which,jpg,max_mae,min_iou,max_mean_diff", [
+    ("scene1", 1, "scene1-camera1.jpg", 0.65, 0.986, 0.6), ("scene1", 2, "scene1-camera2.jpg", 0.72, 0.982, 0.6),
+    ("scene1", 3, "scene1-camera3.jpg", 0.40, 0.961, 0.6), ("scene1", 4, "scene1-camera4.jpg", 0.45, 0.970, 0.6),
+    ("scene2", 1, "scene2-camera1.jpg", 1.15, 0.980, 0.8), ("scene2", 2, "scene2-camera2.jpg", 1.15, 0.984, 0.8),
+    ("scene2", 3, "scene2-camera3.jpg", 1.25, 0.984, 0.8), ("scene3", 1, "scene3.jpg", 1.40, 0.978, 1.5)])
+def test_oracle_matches_course_render(tmp_path, name, which, jpg, max_mae, min_iou, max_mean_diff):
+    from scipy.ndimage import binary_erosion
     s = RefScene(_with_camera(tmp_path, name, which))
     rgb, ids, _, _ = s.render()
     want = np.asarray(Image.open(os.path.join(GOLDEN, jpg)).convert("RGB")).astype(int)
     got = quantize(rgb).astype(int)
     assert got.shape == want.shape == (480, 640, 3)
-    # JPEG ringing and a different renderer: compare coarsely
-    assert np.abs(got - want).mean() < 2.0
+    mae = np.abs(got - want).mean()
     sil_got, sil_want = ids >= 0, want.sum(axis=2) > 24
-    inter, union = (sil_got & sil_want).sum(), (sil_got | sil_want).sum()
-    assert inter / union > min_iou
+    iou = (sil_got & sil_want).sum() / (sil_got | sil_want).sum()
+    inner = binary_erosion(sil_got & sil_want, iterations=4)
+    mean_diff = np.abs(got[inner].mean(axis=0) - want[inner].mean(axis=0)).max()
+    print(f"{name} camera{which}: mean abs error {mae:.3f}, silhouette IoU {iou:.4f}, interior mean colour differs by {mean_diff:.2f}")
+    assert mae < max_mae and iou > min_iou
+    assert inner.sum() > 20000 and mean_diff < max_mean_diff
+    if name == "scene1":
+        # the lit quad: 99 % of its interior pixels within a few 8-bit steps of the course render, channel by channel
+        assert np.percentile(np.abs(got - want)[inner], 99) <= 8
 
 
 # --- grid occupancy figures of the 15^3 reference grid, derived from the scene files alone --------------------------
@@ -168,6 +184,24 @@ def test_oracle_reproduces_golden(name):
     assert [cnt[k] for k in sorted(cnt)] == list(g["counters"])
     bounds, start, cell_ids = s.grid()
     assert np.array_equal(bounds, g["grid_bounds"]) and len(cell_ids) == int(g["grid_refs"])
+
+
+def test_oracle_reproduces_rows_of_the_4k_golden():
+    """The whole-frame 4K golden (tests/golden/make_golden_4k.py, ten CPU-minutes) is too slow to regenerate here; a few
+    of its rows through the dragon are, and pin the committed file to the oracle."""
+    import hashlib
+    g = np.load(os.path.join(GOLDEN, "golden_scene7_4k.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    assert (W, H, int(g["max_depth"])) == (3840, 2160, 5) and g["ids"].shape == (H, W) and g["rgb8"].shape == (H, W, 3)
+    rows = np.arange(1000, H, 400)
+    rgb, ids, _, _ = RefScene(scene_path("scene7")).render(W, H, 5, 1000, 400)
+    assert np.array_equal(ids[rows], g["ids"][rows]) and (g["ids"][rows] >= 0).mean() > 0.2
+    assert np.array_equal(quantize(rgb[rows]), g["rgb8"][rows])
+    assert np.array_equal(rgb[rows].astype(np.float64).sum(axis=(1, 2)), g["rgb_row_sums"][rows])
+    assert len(str(g["rgb_sha256"])) == len(hashlib.sha256(b"").hexdigest())
+    cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    hit = int((g["ids"] >= 0).sum())
+    assert cnt["primary"] == W * H and cnt["shadow"] >= hit and cnt["reflect"] >= hit      # one light; a mirror ray per hit
 
 
 def test_ray_counts_follow_the_hit_counts():

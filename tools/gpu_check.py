@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 from oracle.ref_oracle import RefScene, quantize as ref_quantize
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

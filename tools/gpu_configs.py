@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 from oracle import ref_oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 from oracle.ref_oracle import RefScene
 from test_gpu_parity import _random_scene, FLOAT_TOL
 
@@ -33,15 +34,13 @@ with tempfile.TemporaryDirectory() as tmp:
         r.build_grid(15, int(rng.choice([0, 1, 2, 3, 5, 6])))
         problems = []
         for mode, mode_name in ((rt.SEARCH_NESTED, "nested"), (rt.SEARCH_REFERENCE_LISTS, "reference lists")):
-            os.environ.pop("RTX_FRAME_WAVES", None)
             want_rgb, want_ids, _ = r.render(0, 0, depth, mode, level_queues=True)
             if not np.array_equal(want_ids, ids_ref) or np.abs(want_rgb - rgb_ref).max() > FLOAT_TOL:
                 problems.append(f"{mode_name}: levels vs oracle")
-            for waves in ("3", "4"):
-                for helpers in ("1", "0"):
-                    os.environ["RTX_FRAME_WAVES"], os.environ["RTX_HELPERS"] = waves, helpers
+            for waves in (3, 4):
+                for helpers in (True, False):
                     for k in range(2):
-                        rgb, ids, st = r.render(0, 0, depth, mode)
+                        rgb, ids, st = r.render(0, 0, depth, mode, frame_waves=waves, helpers=helpers)
                         if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
                             problems.append(f"{mode_name}: frame waves={waves} helpers={helpers} pass={k}")
                         if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):

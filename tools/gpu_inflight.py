@@ -10,10 +10,10 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < 8 and "KEEP_HW_QUEUES" n
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 world, depth, wpc = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-os.environ["RTX_BLOCKS_PER_CU"] = str(wpc)
 W, H = 3840, 2160
 sr = rt.SceneReader().readScene(os.path.join(ROOT, "scenes", "scene7.test"))
 rs, streams, bufs = [], [], []
@@ -29,7 +29,7 @@ for _ in range(depth):
 def run(n):
     for k in range(n):
         b = k % depth
-        rs[b].render_device(bufs[b].data_ptr(), 0, W, H, rank=0, world=world, stream=streams[b].cuda_stream)
+        rs[b].render_device(bufs[b].data_ptr(), 0, W, H, rank=0, world=world, stream=streams[b].cuda_stream, workgroups_per_cu=wpc)
     torch.cuda.synchronize()
 
 

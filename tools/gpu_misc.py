@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 scene = sys.argv[1] if len(sys.argv) > 1 else "scene7"

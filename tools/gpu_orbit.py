@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 step = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
@@ -25,17 +26,13 @@ radius = np.linalg.norm((eye - centre)[[0, 2]])
 
 
 def orbit(hint):
-    if hint:
-        os.environ.pop("RTX_TILE_FEEDBACK", None)
-    else:
-        os.environ["RTX_TILE_FEEDBACK"] = "0"
     ms = []
     for k in range(n):
         a = math.radians(step * k)
         cam = sr._camera()
         cam.eye[0] = float(centre[0] + radius * math.sin(a))
         cam.eye[2] = float(centre[2] + radius * math.cos(a))
-        st = r.render_device(d_rgb.data_ptr(), 0, W, H, camera=cam, want_stats=True)
+        st = r.render_device(d_rgb.data_ptr(), 0, W, H, camera=cam, want_stats=True, tile_hint=hint)
         ms.append(st.frame_ms)
     return np.array(ms)
 

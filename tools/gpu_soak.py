@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 r = rt.Renderer(0)
@@ -29,15 +30,13 @@ for name, sub, W, H, mode in cases:
     r.render_device(want.data_ptr(), want_ids.data_ptr(), W, H, 5, mode, level_queues=True)
     torch.cuda.synchronize()
     differ = 0
-    for waves in ("3", "4"):
-        os.environ["RTX_FRAME_WAVES"] = waves
+    for waves in (3, 4):
         for k in range(n):
             got.fill_(-1.0)
-            r.render_device(got.data_ptr(), got_ids.data_ptr(), W, H, 5, mode)
+            r.render_device(got.data_ptr(), got_ids.data_ptr(), W, H, 5, mode, frame_waves=waves)
             torch.cuda.synchronize()
             if not (torch.equal(got.view(torch.int32), want.view(torch.int32)) and torch.equal(got_ids, want_ids)):
                 differ += 1
-    os.environ.pop("RTX_FRAME_WAVES", None)
     bad += differ
     print(f"{name} {W}x{H} mode {mode}: {2 * n} frames, {differ} differ", flush=True)
 r.close()

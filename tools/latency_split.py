@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 W, H = 3840, 2160
 sr = rt.SceneReader().readScene('/root/repo/scenes/scene7.test')
 r = rt.Renderer(0); r.set_scene(sr); r.build_grid(15, 6)

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 import raytracer_amd as rt
+import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 wg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -24,10 +25,10 @@ r.build_grid(15, 6)
 d_rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 for _ in range(2):
     r.render_device(d_rgb.data_ptr(), 0, W, H, rank=0, world=world, workgroups_per_cu=wg)
-os.environ["RTX_WAVE_LOG"] = out
 st = r.render_device(d_rgb.data_ptr(), 0, W, H, rank=0, world=world, want_stats=True, count_work=True, workgroups_per_cu=wg)
-del os.environ["RTX_WAVE_LOG"]
-a = np.loadtxt(out, delimiter=",", skiprows=1)
+log = r.wave_log().astype(np.float64)
+a = np.concatenate([np.arange(len(log))[:, None], log], axis=1)      # column 0: wave number
+np.savetxt(out, a, delimiter=",", header="wave,start,exhausted,end,rounds,updates,pixels,deepest,helper_tasks", comments="")
 a = a[a[:, 3] > 0]                                  # waves that ran
 t0 = a[:, 1].min()
 start, exh, end = (a[:, 1] - t0) / 100.0, (a[:, 2] - t0) / 100.0, (a[:, 3] - t0) / 100.0      # microseconds
