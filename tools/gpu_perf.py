@@ -19,6 +19,7 @@ W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3840, 216
 subs = [int(s) for s in sys.argv[4].split(",")] if len(sys.argv) > 4 else [8, 12]
 do_ref = "noref" not in sys.argv
 do_serial = "noserial" not in sys.argv
+do_levels = "nolevels" not in sys.argv
 sr = rt.SceneReader().readScene(os.path.join(ROOT, "scenes", scene + ".test"))
 r = rt.Renderer(0)
 r.set_scene(sr)
@@ -55,7 +56,8 @@ for sub in subs:
     print(f"sub={gi.sub}: fine cells {gi.n_fine_cells} occupied {gi.n_occupied_fine_cells} refs {gi.n_fine_refs} "
           f"build {gi.build_ms:.1f} ms", flush=True)
     run(rt.SEARCH_NESTED, False, f"  nested sub={gi.sub} frame ", lq=False)
-    run(rt.SEARCH_NESTED, False, f"  nested sub={gi.sub} levels")
+    if do_levels:
+        run(rt.SEARCH_NESTED, False, f"  nested sub={gi.sub} levels")
     if do_serial:
         run(rt.SEARCH_NESTED, True, f"  nested sub={gi.sub} serial")
 if do_ref:
