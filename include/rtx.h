@@ -218,6 +218,20 @@ int  rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows);
 int  rtx_render(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                 float* rgb_out, int32_t* prim_id_out, rtx_stats* stats);
 
+/* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  The call allocates nothing and frees nothing, on
+ * the host or on the device: the work cursors, the screen-tile map / classes / list / per-tile depths and the path
+ * terms beyond the levels kept in LDS -- which rtx_render_device keeps in buffers the context allocates on first use --
+ * live in a 10.2 MB array the library holds on every GPU it runs on for the life of the process.
+ *   Limits (RTX_E_LIMIT beyond): max_depth <= 6; ceil(width / 8) * ceil(height / 8) <= 131072 (3840 x 2160 fits).
+ *   Not available (RTX_E_INVALID): RTX_RENDER_LEVEL_QUEUES, RTX_RENDER_SERIAL_LANES, RTX_RENDER_COUNT_WORK; no stats.
+ *   At most 1024 workgroups are launched (workgroups_per_cu is clamped).
+ * The scene and grid must be set before (rtx_set_scene, rtx_build_grid: those do allocate).  Results are those of
+ * rtx_render_device bit for bit.  All contexts of a GPU share that GPU's array: calls that overlap in time on one
+ * GPU, from whatever contexts or streams, race on it and must be serialised by the caller. */
+int  rtx_render_device_noalloc(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
+                               float* d_rgb_local, int32_t* d_prim_id_local, void* stream);
+
 /* A frame is abandoned when a wave of the persistent frame kernel exceeds rtx_render_params.round_limit: its
  * remaining pixels keep the fill colour.  rtx_render and rtx_render_device with `stats` report that as RTX_E_LIMIT
  * themselves; after an asynchronous rtx_render_device this call waits for the context's last frame and returns

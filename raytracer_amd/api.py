@@ -134,6 +134,7 @@ def _load():
         "rtx_render": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, C.POINTER(RenderStats)]),
         "rtx_render_device": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp,
                                         C.POINTER(RenderStats)]),
+        "rtx_render_device_noalloc": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp]),
         "rtx_frame_status": (C.c_int, [vp]),
         "rtx_download_wave_log": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
         "rtx_intersect": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = (
     "rtx_strerror", "rtx_last_error", "rtx_scene_load", "rtx_scene_parse", "rtx_scene_free", "rtx_scene_get_view",
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
-    "rtx_render_device", "rtx_frame_status", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
     "rtx_save_image")
 
 
@@ -358,6 +359,16 @@ class Renderer:
                                          C.c_void_p(stream) if stream else None,
                                          C.byref(st) if st is not None else None))
         return st
+
+    def render_device_noalloc(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8,
+                              rank=0, world=1, stream=None, camera=None, eps_bias=SceneReader.epsilonBias, workgroups_per_cu=0,
+                              flags=0, **sched):
+        """render_device through the entry point that allocates nothing (scratch in the library's per-GPU array)."""
+        cam = camera if camera is not None else self.scene._camera()
+        p = _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu, **sched)
+        _check(_load().rtx_render_device_noalloc(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_rgb_ptr),
+                                                 C.c_void_p(d_ids_ptr) if d_ids_ptr else None,
+                                                 C.c_void_p(stream) if stream else None))
 
     def frame_status(self):
         """Waits for this context's last asynchronous frame; raises RtxError (RTX_E_LIMIT) if it was abandoned."""

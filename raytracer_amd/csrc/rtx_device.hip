@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -50,6 +51,28 @@ using namespace rt;
 #include "rtx_kernels_grid.h"
 
 // ---------------------------------------------------------------------------------------------------
+// Scratch of rtx_render_device_noalloc: everything the persistent frame pipeline needs beyond the caller's buffers
+// (work cursors and counters, the screen-tile map / classes / list / per-tile path depths, the strips of path terms
+// deeper than the levels held in LDS), carved out of one file-scope device array.  Every GPU the library runs on
+// holds its own copy until the process ends; host code reaches it only through the address hipGetSymbolAddress
+// returns for the current device (kept per context), never through the array's name.
+// ---------------------------------------------------------------------------------------------------
+#define RTX_NOALLOC_MAX_TILES (1 << 17)            // 8x8 pixel tiles of the whole image: 3840 x 2160 has 129 600
+#define RTX_NOALLOC_MAX_BLOCKS 1024                // workgroups of the frame kernel (256 CUs x 4)
+#define RTX_NOALLOC_GLOBAL_LEVELS 2                // path levels beyond those in LDS: max_depth <= 6
+#define RTX_NOALLOC_MAX_DEPTH 6
+#define RTX_NA_ALIGN(x) (((size_t)(x) + 255) & ~(size_t)255)
+#define RTX_NA_COUNTERS 0
+#define RTX_NA_TILE_MAP (RTX_NA_COUNTERS + RTX_NA_ALIGN(CNT_TOTAL * sizeof(int)))
+#define RTX_NA_TILE_CLASS (RTX_NA_TILE_MAP + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES + 16))
+#define RTX_NA_TILE_LIST (RTX_NA_TILE_CLASS + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES))
+#define RTX_NA_TILE_COST0 (RTX_NA_TILE_LIST + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES * sizeof(int)))
+#define RTX_NA_TILE_COST1 (RTX_NA_TILE_COST0 + RTX_NA_ALIGN((RTX_NOALLOC_MAX_TILES + 4) * sizeof(int)))
+#define RTX_NA_PATH_STACK (RTX_NA_TILE_COST1 + RTX_NA_ALIGN((RTX_NOALLOC_MAX_TILES + 4) * sizeof(int)))
+#define RTX_NOALLOC_SCRATCH_BYTES (RTX_NA_PATH_STACK + (size_t)RTX_NOALLOC_MAX_BLOCKS * RTX_BLOCK * RTX_NOALLOC_GLOBAL_LEVELS * sizeof(float4))
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];   // 10.2 MB
+
+// ---------------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
@@ -78,6 +101,24 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
+};
+
+// Buffers of the persistent frame pipeline beyond the caller's: a context's own allocations, or the device's scratch
+struct FrameScratch {
+    int* counters = nullptr;
+    unsigned long long* work = nullptr;            // instrumented frames only
+    float4* path_stack = nullptr;
+    unsigned char* tile_map = nullptr;
+    signed char* tile_class = nullptr;
+    int* tile_list = nullptr;
+    int* tile_cost[2] = {nullptr, nullptr};
+};
+// What the per-tile path depths in a pair of cost maps belong to
+struct HintState {
+    int key[6] = {0, 0, 0, 0, 0, 0};   // W, H, tile_rows, rank, world, grid generation the cost map was recorded for
+    rtx_camera cam{};                   // ... and the camera it was recorded under
+    int cur = 0;                        // tile_cost[cur] was written by the last frame
+    bool valid = false;
 };
 
 struct rtx_ctx {
@@ -113,10 +154,9 @@ struct rtx_ctx {
     DevBuf<unsigned char> tile_map;
     DevBuf<signed char> tile_class;
     DevBuf<int> tile_list, tile_cost[2];
-    int cost_key[6] = {0, 0, 0, 0, 0, 0};   // W, H, tile_rows, rank, world, grid generation the cost map belongs to
-    rtx_camera cost_cam{};        // ... and the camera it was recorded under
-    int cost_cur = 0;             // tile_cost[cost_cur] was written by the last frame
-    bool cost_valid = false;
+    HintState hint;               // of the context's own cost maps
+    HintState scratch_hint;       // of the device scratch's cost maps, while this context was its last user
+    unsigned char* scratch = nullptr;   // device address of this GPU's copy of the scratch array
     int grid_generation = 0;
     float fine_pad = 0.0f;        // margin the nested lists were binned with
     DevBuf<float> rgb_local;
@@ -132,6 +172,25 @@ struct rtx_ctx {
 };
 
 namespace {
+
+// Which context used a device's scratch array last (its cost maps then still hold that context's per-tile depths).
+#define RTX_MAX_DEVICES 64
+std::mutex g_scratch_mutex;
+const rtx_ctx* g_scratch_user[RTX_MAX_DEVICES] = {};
+// Makes `c` the scratch's user on its device; true if it already was.
+bool scratch_take_over(const rtx_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    const int d = c->device;
+    if (d < 0 || d >= RTX_MAX_DEVICES) return false;
+    const bool mine = g_scratch_user[d] == c;
+    g_scratch_user[d] = c;
+    return mine;
+}
+void scratch_forget(const rtx_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    for (auto& u : g_scratch_user)
+        if (u == c) u = nullptr;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -295,31 +354,32 @@ void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level
 }
 
 template <int MODE, bool SINGLE_XF, int PRIMS, int WAVES>
-void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels) {
-    float4* ps = c->path_stack.p;
+void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels) {
     if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
     else hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
 }
 
 template <int MODE, bool SINGLE_XF, int PRIMS>
-void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels, int waves) {
-    if (waves >= 4) launch_frame4<MODE, SINGLE_XF, PRIMS, 4>(c, sc, f, blocks, st, count, levels);
-    else launch_frame4<MODE, SINGLE_XF, PRIMS, 3>(c, sc, f, blocks, st, count, levels);
+void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves) {
+    if (waves >= 4) launch_frame4<MODE, SINGLE_XF, PRIMS, 4>(c, sc, f, ps, blocks, st, count, levels);
+    else launch_frame4<MODE, SINGLE_XF, PRIMS, 3>(c, sc, f, ps, blocks, st, count, levels);
 }
 
+// (`levels` = entries per lane of the strip `ps` of path terms kept in global memory; both builds index it from their
+// own first global level, so the strip sized for the four-wave build also serves the three-wave one)
 // picks the kernel specialisation for the scene: one transform or many, triangles only / spheres only / both
 template <int MODE>
-void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int blocks, hipStream_t st, bool count, int levels, int waves) {
+void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves) {
     const bool single = c->n_xforms == 1;
     const int prims = c->n_spheres == 0 ? 1 : (c->n_triangles == 0 ? 2 : 0);
     if (single) {
-        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, blocks, st, count, levels, waves);
-        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, blocks, st, count, levels, waves);
-        else launch_frame3<MODE, true, 0>(c, sc, f, blocks, st, count, levels, waves);
+        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, ps, blocks, st, count, levels, waves);
+        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, ps, blocks, st, count, levels, waves);
+        else launch_frame3<MODE, true, 0>(c, sc, f, ps, blocks, st, count, levels, waves);
     } else {
-        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, blocks, st, count, levels, waves);
-        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, blocks, st, count, levels, waves);
-        else launch_frame3<MODE, false, 0>(c, sc, f, blocks, st, count, levels, waves);
+        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, ps, blocks, st, count, levels, waves);
+        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, ps, blocks, st, count, levels, waves);
+        else launch_frame3<MODE, false, 0>(c, sc, f, ps, blocks, st, count, levels, waves);
     }
 }
 
@@ -376,6 +436,18 @@ int rtx_create(rtx_ctx** out, int device_id) {
         return RTX_E_NOMEM;
     }
     *c->abort_host = 0;
+    // This GPU's copy of the scratch array of rtx_render_device_noalloc: its address is a property of the device, asked
+    // for once per context with that device current.  The array's name itself is never used as an address on the host.
+    {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            rtx_set_error("rtx_create: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+            rtx_destroy(c);
+            return RTX_E_DEVICE;
+        }
+        c->scratch = (unsigned char*)ptr;
+    }
     *out = c;
     return RTX_OK;
 }
@@ -387,6 +459,7 @@ void rtx_destroy(rtx_ctx* c) {
     if (c->have_events)
         for (auto& ev : c->ev) (void)hipEventDestroy(ev);
     if (c->abort_host) (void)hipHostFree(c->abort_host);
+    scratch_forget(c);
     delete c;                     // every DevBuf releases its memory
 }
 
@@ -678,9 +751,12 @@ int rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows) {
     return RTX_OK;
 }
 
-int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* d_rgb, int32_t* d_ids,
-                      void* stream, rtx_stats* stats) {
-    if (!c || !cam || !d_rgb) { rtx_set_error("rtx_render_device: null argument"); return RTX_E_INVALID; }
+// One frame of this rank's rows, enqueued on `stream`.  no_alloc: the entry point that allocates nothing -- the
+// persistent frame pipeline only, its scratch taken from the device's file-scope array instead of the context's own
+// buffers, sizes beyond that array rejected, no statistics.
+static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* d_rgb, int32_t* d_ids,
+                        void* stream, rtx_stats* stats, bool no_alloc) {
+    if (!c || !cam || !d_rgb) { rtx_set_error("render: null argument"); return RTX_E_INVALID; }
     int tile_rows, rank, world;
     int rc = check_params(p, &tile_rows, &rank, &world);
     if (rc) return rc;
@@ -699,13 +775,46 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
-    if (level_queues) {
+    // path levels that do not fit the frame kernel's LDS strips (five levels in its four-wave build) live in global memory
+    const int global_levels = std::max(levels - FrameBudget<4>::lds_levels, 1);
+    const int tbx = (p->width + 7) / 8, tby = (p->height + 7) / 8;
+    FrameScratch ws;
+    HintState* hint = &c->hint;
+    if (no_alloc) {
+        if (level_queues || (p->flags & RTX_RENDER_COUNT_WORK)) {
+            rtx_set_error("rtx_render_device_noalloc: the level-queue pipelines and the work counters need allocated workspace");
+            return RTX_E_INVALID;
+        }
+        if (p->max_depth > RTX_NOALLOC_MAX_DEPTH || (long long)tbx * tby > RTX_NOALLOC_MAX_TILES) {
+            rtx_set_error("rtx_render_device_noalloc: max_depth %d / %lld screen tiles exceed the scratch array's limits (max_depth <= %d, "
+                          "ceil(width/8) * ceil(height/8) <= %d)", p->max_depth, (long long)tbx * tby, RTX_NOALLOC_MAX_DEPTH, RTX_NOALLOC_MAX_TILES);
+            return RTX_E_LIMIT;
+        }
+        if (!c->scratch) { rtx_set_error("rtx_render_device_noalloc: the device scratch array was not found at rtx_create"); return RTX_E_STATE; }
+        blocks = std::min(blocks, RTX_NOALLOC_MAX_BLOCKS);
+        unsigned char* base = c->scratch;
+        ws.counters = (int*)(base + RTX_NA_COUNTERS);
+        ws.tile_map = base + RTX_NA_TILE_MAP;
+        ws.tile_class = (signed char*)(base + RTX_NA_TILE_CLASS);
+        ws.tile_list = (int*)(base + RTX_NA_TILE_LIST);
+        ws.tile_cost[0] = (int*)(base + RTX_NA_TILE_COST0);
+        ws.tile_cost[1] = (int*)(base + RTX_NA_TILE_COST1);
+        ws.path_stack = (float4*)(base + RTX_NA_PATH_STACK);
+        // the scratch's cost maps only carry a hint for this context if no other context of the device used them since
+        if (!scratch_take_over(c)) c->scratch_hint.valid = false;
+        hint = &c->scratch_hint;
+    } else if (level_queues) {
         if ((rc = ensure_workspace(c, std::max(pixels, (size_t)1), levels))) return rc;
+        ws.counters = c->counters.p;
+        ws.work = c->work.p;
     } else {
         // (instrumented frames log eight values per wave behind the 24 work counters)
         if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24 + 8 * (size_t)blocks * (RTX_BLOCK / 64))) ||
-            (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * levels)))
+            (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * global_levels)))
             return rc;
+        ws.counters = c->counters.p;
+        ws.work = c->work.p;
+        ws.path_stack = c->path_stack.p;
     }
     if (stats) memset(stats, 0, sizeof *stats);
     if (nl == 0) return RTX_OK;
@@ -737,7 +846,6 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.n_items0 = f.nbx * ((lr_end - f.lr0 + 7) / 8) * 64;
     bool whole_frame = f.lr0 == 0 && lr_end == nl && f.bx0 == 0 && f.nbx == (p->width + 7) / 8;
     // nested search, persistent kernel: only the tiles of the window that can see an occupied fine cell are traced
-    const int tbx = (p->width + 7) / 8, tby = (p->height + 7) / 8;
     const int n_row_blocks = f.n_items0 > 0 ? (lr_end - f.lr0 + 7) / 8 : 0;
     // Register budget of the frame kernel: with many pixels of the traced window per lane of the launch the frame is
     // bound by throughput and four waves per SIMD win (measured on scene7: 4K frame 2.16 against 2.35 ms); with few
@@ -751,13 +859,20 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
     if (p->flags & RTX_RENDER_NO_TILE_CULL) tile_cull = false;
     if (tile_cull) {
-        const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
-        // + 16 bytes: the clear kernel writes whole 16-byte words
-        if ((rc = c->tile_map.reserve((size_t)tbx * tby + 16)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
-            (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots + 4)) ||
-            (rc = c->tile_cost[1].reserve(n_slots + 4)))
-            return rc;
-        f.tile_list = c->tile_list.p;
+        if (!no_alloc) {
+            const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
+            // + 16 bytes: the clear kernel writes whole 16-byte words
+            if ((rc = c->tile_map.reserve((size_t)tbx * tby + 16)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
+                (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots + 4)) ||
+                (rc = c->tile_cost[1].reserve(n_slots + 4)))
+                return rc;
+            ws.tile_map = c->tile_map.p;
+            ws.tile_class = c->tile_class.p;
+            ws.tile_list = c->tile_list.p;
+            ws.tile_cost[0] = c->tile_cost[0].p;
+            ws.tile_cost[1] = c->tile_cost[1].p;
+        }
+        f.tile_list = ws.tile_list;
         f.tbx = tbx;
         whole_frame = false;
     }
@@ -771,8 +886,8 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     f.abort_host = c->abort_dev;
     f.rgb = d_rgb;
     f.ids = d_ids;
-    f.counters = c->counters.p;
-    f.work = c->work.p;
+    f.counters = ws.counters;
+    f.work = ws.work;
     if (level_queues) { f.hP = c->hP.p; f.hN = c->hN.p; f.hD = c->hD.p; f.pix0 = c->pix0.p; }
 
     const DevScene sc = dev_scene(c);
@@ -786,7 +901,9 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
     {
         ClearRanges cr;
         memset(&cr, 0, sizeof cr);
+        bool clear_overflow = false;
         auto add = [&](void* ptr, size_t bytes, unsigned pattern) {
+            if (cr.n >= RTX_CLEAR_RANGES) { clear_overflow = true; return; }
             cr.ptr[cr.n] = (uint4*)ptr; cr.words[cr.n] = (long long)((bytes + 15) / 16); cr.pattern[cr.n] = pattern; cr.n++;
         };
         if (!whole_frame) {
@@ -798,14 +915,15 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
                 else HIP_TRY(hipMemsetAsync(d_ids, 0xff, id_bytes, st));
             }
         }
-        add(c->counters.p, CNT_TOTAL * sizeof(int), 0u);
-        if (count) add(c->work.p, 24 * sizeof(unsigned long long), 0u);
+        add(ws.counters, CNT_TOTAL * sizeof(int), 0u);
+        if (count) add(ws.work, 24 * sizeof(unsigned long long), 0u);
         if (tile_cull) {
             // the map this frame records its per-block path depths into (the other one orders this frame's list)
-            c->cost_cur ^= 1;
-            add(c->tile_map.p, (size_t)tbx * tby, 0u);
-            add(c->tile_cost[c->cost_cur].p, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), 0u);
+            hint->cur ^= 1;
+            add(ws.tile_map, (size_t)tbx * tby, 0u);
+            add(ws.tile_cost[hint->cur], (size_t)tbx * ((nl + 7) / 8) * sizeof(int), 0u);
         }
+        if (clear_overflow) { rtx_set_error("render: more ranges to clear than the clear kernel takes"); return RTX_E_STATE; }
         long long total = 0;
         for (int k = 0; k < cr.n; k++) total += cr.words[k];
         const int clear_blocks = (int)std::min<long long>((total + 255) / 256, (long long)c->n_cus * 16);
@@ -815,29 +933,29 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         const int n_occ = (int)c->ginfo.n_occupied_fine_cells;
         if (n_occ > 0)
             hipLaunchKernelGGL(k_tile_mark, dim3((n_occ + 255) / 256), dim3(256), 0, st, f.cam, c->dgrid, (const int*)c->ocell.p, c->fine_pad,
-                               n_occ, tbx, tby, c->tile_map.p, c->counters.p);
+                               n_occ, tbx, tby, ws.tile_map, ws.counters);
         // the previous frame's per-block path depths order this frame's list if they were recorded for the same
         // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
         const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
-        const bool feedback = c->cost_valid && memcmp(key, c->cost_key, sizeof key) == 0 && !(p->flags & RTX_RENDER_NO_TILE_HINT);
-        const int* prev_cost = feedback ? c->tile_cost[c->cost_cur ^ 1].p : nullptr;
+        const bool feedback = hint->valid && memcmp(key, hint->key, sizeof key) == 0 && !(p->flags & RTX_RENDER_NO_TILE_HINT);
+        const int* prev_cost = feedback ? ws.tile_cost[hint->cur ^ 1] : nullptr;
         // a tile takes the deepest class recorded within hint_radius tiles around it: one tile allows for a camera
         // that moved a little; the very same camera needs no allowance (4K frame of scene7: 2.08 against 2.19 ms)
-        f.hint_radius = feedback && memcmp(cam, &c->cost_cam, sizeof *cam) == 0 ? 0 : 1;
-        c->cost_cam = *cam;
-        f.tile_cost = c->tile_cost[c->cost_cur].p;
-        memcpy(c->cost_key, key, sizeof key);
-        c->cost_valid = true;
+        f.hint_radius = feedback && memcmp(cam, &hint->cam, sizeof *cam) == 0 ? 0 : 1;
+        hint->cam = *cam;
+        f.tile_cost = ws.tile_cost[hint->cur];
+        memcpy(hint->key, key, sizeof key);
+        hint->valid = true;
         const int n_blocks_window = n_row_blocks * f.nbx;
         hipLaunchKernelGGL(k_tile_classify, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
-                           (const unsigned char*)c->tile_map.p, prev_cost, c->tile_class.p);
+                           (const unsigned char*)ws.tile_map, prev_cost, ws.tile_class);
         hipLaunchKernelGGL(k_tile_fill, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
-                           (const signed char*)c->tile_class.p, c->tile_list.p);
+                           (const signed char*)ws.tile_class, ws.tile_list);
     }
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
-        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, blocks, st, count, levels, frame_waves);
-        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, blocks, st, count, levels, frame_waves);
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, ws.path_stack, blocks, st, count, global_levels, frame_waves);
+        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, ws.path_stack, blocks, st, count, global_levels, frame_waves);
         HIP_TRY(hipEventRecord(ev[1], st));
     }
     for (int l = 0; level_queues && l < levels; l++) {
@@ -865,7 +983,7 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         if ((rc = take_frame_status(c, true))) return rc;
         HIP_TRY(hipEventSynchronize(ev[2]));
         int cnt[CNT_TOTAL];
-        HIP_TRY(hipMemcpyAsync(cnt, c->counters.p, sizeof cnt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cnt, ws.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         stats->primary_rays = (int64_t)pixels;
         // the level-synchronous pipelines walk every pixel's camera ray
@@ -906,6 +1024,15 @@ int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params
         }
     }
     return RTX_OK;
+}
+
+int rtx_render_device(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* d_rgb, int32_t* d_ids,
+                      void* stream, rtx_stats* stats) {
+    return render_frame(c, cam, p, d_rgb, d_ids, stream, stats, false);
+}
+
+int rtx_render_device_noalloc(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* d_rgb, int32_t* d_ids, void* stream) {
+    return render_frame(c, cam, p, d_rgb, d_ids, stream, nullptr, true);
 }
 
 int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* rgb_out, int32_t* prim_id_out, rtx_stats* stats) {

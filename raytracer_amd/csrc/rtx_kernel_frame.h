@@ -26,7 +26,7 @@ struct FrameBudget {
 };
 
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
-__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int levels) {
+__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int global_levels) {
     constexpr int RTX_LDS_LEVELS = FrameBudget<WAVES>::lds_levels;
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ float4 stack_lds[RTX_BLOCK / 64][RTX_LDS_LEVELS][64];
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
     // per-level terms of this lane's path: the first RTX_LDS_LEVELS levels (where nearly all hits are) in LDS, deeper
-    // ones in a private strip of global memory
-    float4* stack_g = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * levels;
+    // ones in a private strip of global memory (global_levels entries per lane, entry 0 = level RTX_LDS_LEVELS)
+    float4* stack_g = path_stack + ((size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 64 + lane) * global_levels;
     WorkCounters wc = {};
 
     // path state of this lane; the ray in flight lives in the walker (w.O, w.D, w.t_limit)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         const float* m = sc.mats + 16 * material;
                         const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
                         const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-                        if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level] = rec;
+                        if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level - RTX_LDS_LEVELS] = rec;
                     }
                     if (level < f.max_depth) {
                         const f3 V = normalize3(-rayDir);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     };
                     // one loop per address space: a pointer selected inside a single loop would turn every read into a
                     // flat load
-                    for (int d = top; d >= RTX_LDS_LEVELS; d--) fold(stack_g[d]);
+                    for (int d = top; d >= RTX_LDS_LEVELS; d--) fold(stack_g[d - RTX_LDS_LEVELS]);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const __attribute__((address_space(3))) float* sl =
                         (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];

@@ -4,13 +4,14 @@
 
 // ---------------------------------------------------------------------------------------------------
 // Start of a frame in one launch: the miss colour (0) over the colour buffer, -1 over the id map, zeros over the
-// counters and the tile maps.  Up to six (pointer, 16-byte words, 32-bit pattern) ranges, each a multiple of 16
+// counters and the tile maps.  Up to RTX_CLEAR_RANGES (pointer, 16-byte words, 32-bit pattern) ranges, each a multiple of 16
 // bytes long and 16-byte aligned (device allocations are; the host rounds the lengths up inside the allocations).
 // ---------------------------------------------------------------------------------------------------
+#define RTX_CLEAR_RANGES 8
 struct ClearRanges {
-    uint4* ptr[6];
-    long long words[6];
-    unsigned pattern[6];
+    uint4* ptr[RTX_CLEAR_RANGES];
+    long long words[RTX_CLEAR_RANGES];
+    unsigned pattern[RTX_CLEAR_RANGES];
     int n;
 };
 __global__ __launch_bounds__(256) void k_frame_clear(ClearRanges r) {
