@@ -218,6 +218,12 @@ int  rtx_local_rows(const rtx_render_params* p, int32_t* n_rows, int32_t* rows);
 int  rtx_render(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                 float* rgb_out, int32_t* prim_id_out, rtx_stats* stats);
 
+/* The same with the image converted to 8 bits per channel on the device before it crosses to the host -- the image the
+ * reference saves (Image3f::save via get_3b_bgr_buffer, src/Image3f.h:128-133,154-170: order RTX_ORDER_BGR; write3fPpm,
+ * :63-80: RTX_ORDER_RGB), a quarter of the bytes of the float frame.  rgb8_out: width*height*3 bytes. */
+int  rtx_render_u8(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
+                   uint8_t* rgb8_out, int32_t order, int32_t* prim_id_out, rtx_stats* stats);
+
 /* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference.  The call allocates nothing and frees nothing, on
  * the host or on the device: the work cursors, the screen-tile map / classes / list / per-tile depths and the path
@@ -261,6 +267,31 @@ int  rtx_camera_rays(rtx_ctx* ctx, const rtx_camera* cam, int32_t width, int32_t
                      const int32_t* xy, float* dirs);
 
 /* ------------------------------------------------------------------------------------------------
+ * Several GPUs of one node behind one handle.  The reference has no counterpart (its only parallelism is OpenMP over the
+ * rows of the pixel loop, src/main.cpp:126).  The scene and its grid are replicated on every GPU, the frame is split
+ * into interleaved tiles of `tile_rows` rows (tile t -> the (t mod N)-th device), every GPU renders its tiles and copies
+ * them into the frame on the first GPU over its point-to-point link to it; rank and world of rtx_render_params are
+ * ignored.  Frames are bit-identical to one GPU's.  A device id may be listed more than once (the ranks then share
+ * that GPU).  Not thread-safe per handle.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rtx_multi rtx_multi;
+int  rtx_multi_create(rtx_multi** out, const int32_t* device_ids, int32_t n_devices);
+void rtx_multi_destroy(rtx_multi* m);
+int  rtx_multi_device_count(const rtx_multi* m);
+int  rtx_multi_set_scene(rtx_multi* m, const rtx_scene_view* view);
+int  rtx_multi_build_grid(rtx_multi* m, int32_t rx, int32_t ry, int32_t rz, int32_t sub, uint32_t flags);
+int  rtx_multi_get_grid_info(const rtx_multi* m, rtx_grid_info* out);          /* of the first GPU's copy */
+/* rgb_out / rgb8_out / prim_id_out: the whole image in host memory, as for rtx_render / rtx_render_u8.  stats
+ * (nullable): ray counts summed over the GPUs, trace_ms of the slowest GPU's kernel, frame_ms host wall time. */
+int  rtx_multi_render(rtx_multi* m, const rtx_camera* cam, const rtx_render_params* p,
+                      float* rgb_out, int32_t* prim_id_out, rtx_stats* stats);
+int  rtx_multi_render_u8(rtx_multi* m, const rtx_camera* cam, const rtx_render_params* p,
+                         uint8_t* rgb8_out, int32_t order, int32_t* prim_id_out, rtx_stats* stats);
+/* d_rgb (width*height*3 floats) / d_prim_id (nullable): device memory of the FIRST listed GPU; complete on return. */
+int  rtx_multi_render_device(rtx_multi* m, const rtx_camera* cam, const rtx_render_params* p,
+                             float* d_rgb, int32_t* d_prim_id, rtx_stats* stats);
+
+/* ------------------------------------------------------------------------------------------------
  * Image output -- replaces Image3f::write3fPpm / save (src/Image3f.h:63-80,128-133,154-170) without OpenCV.
  * Conversion to 8 bits truncates, (unsigned char)(clamp(c) * 255), as the reference does (:72-74,163-165).
  * ---------------------------------------------------------------------------------------------- */
@@ -275,6 +306,8 @@ int  rtx_quantize(const float* rgb, int64_t n_values, uint8_t* out);
 int  rtx_quantize_device(rtx_ctx* ctx, const float* d_rgb, int64_t n_pixels, uint8_t* d_out, int32_t order, void* stream);
 /* Format by extension: .png (8-bit RGB, zlib deflate) or .ppm (P6). */
 int  rtx_save_image(const char* path, const float* rgb, int32_t width, int32_t height);
+/* The same from an image that already is 8 bits per channel, RGB order (e.g. rtx_render_u8's output). */
+int  rtx_save_image_u8(const char* path, const uint8_t* rgb8, int32_t width, int32_t height);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,7 @@ without a HIP device raises.
 from .api import (  # noqa: F401
     GridInfo,
     Image3f,
+    MultiRenderer,
     Renderer,
     RenderStats,
     RtxError,

@@ -132,6 +132,17 @@ def _load():
         "rtx_download_grid": (C.c_int, [vp, C.c_uint32, vp, vp]),
         "rtx_local_rows": (C.c_int, [C.POINTER(_RenderParams), C.POINTER(i32), vp]),
         "rtx_render": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, C.POINTER(RenderStats)]),
+        "rtx_render_u8": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, i32, vp, C.POINTER(RenderStats)]),
+        "rtx_multi_create": (C.c_int, [C.POINTER(vp), vp, i32]),
+        "rtx_multi_destroy": (None, [vp]),
+        "rtx_multi_device_count": (C.c_int, [vp]),
+        "rtx_multi_set_scene": (C.c_int, [vp, C.POINTER(_SceneView)]),
+        "rtx_multi_build_grid": (C.c_int, [vp, i32, i32, i32, i32, C.c_uint32]),
+        "rtx_multi_get_grid_info": (C.c_int, [vp, C.POINTER(GridInfo)]),
+        "rtx_multi_render": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, C.POINTER(RenderStats)]),
+        "rtx_multi_render_u8": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, i32, vp, C.POINTER(RenderStats)]),
+        "rtx_multi_render_device": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, C.POINTER(RenderStats)]),
+        "rtx_save_image_u8": (C.c_int, [C.c_char_p, vp, i32, i32]),
         "rtx_render_device": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp,
                                         C.POINTER(RenderStats)]),
         "rtx_render_device_noalloc": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp]),
@@ -156,7 +167,9 @@ EXPORTED_SYMBOLS = (
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
     "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
-    "rtx_save_image")
+    "rtx_save_image", "rtx_render_u8", "rtx_save_image_u8", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_device_count",
+    "rtx_multi_set_scene", "rtx_multi_build_grid", "rtx_multi_get_grid_info", "rtx_multi_render", "rtx_multi_render_u8",
+    "rtx_multi_render_device")
 
 
 def _check(rc):
@@ -345,6 +358,21 @@ class Renderer:
         _check(_load().rtx_render(self._h, C.byref(cam), C.byref(p), _ptr(rgb), _ptr(ids), C.byref(st)))
         return rgb, ids, st
 
+    def render_u8(self, width=0, height=0, max_depth=5, search=SEARCH_NESTED, bgr=False, want_ids=False, camera=None,
+                  eps_bias=SceneReader.epsilonBias, **sched):
+        """The frame converted to 8 bits per channel on the device; returns (rgb8[H,W,3] uint8, ids or None, stats)."""
+        sc = self.scene
+        W = width if width > 0 else sc.width
+        H = height if height > 0 else sc.height
+        cam = camera if camera is not None else sc._camera()
+        p = _params(W, H, max_depth, eps_bias, search, 8, 0, 1, 0, **sched)
+        rgb8 = np.zeros((H, W, 3), np.uint8)
+        ids = np.full((H, W), -2, np.int32) if want_ids else None
+        st = RenderStats()
+        _check(_load().rtx_render_u8(self._h, C.byref(cam), C.byref(p), _ptr(rgb8), ORDER_BGR if bgr else ORDER_RGB, _ptr(ids),
+                                     C.byref(st)))
+        return rgb8, ids, st
+
     def render_device(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8,
                       rank=0, world=1, stream=None, want_stats=False, count_work=False, camera=None,
                       eps_bias=SceneReader.epsilonBias, serial_lanes=False, level_queues=False, workgroups_per_cu=0, **sched):
@@ -407,6 +435,70 @@ class Renderer:
         out = np.zeros((len(xy), 3), np.float32)
         _check(_load().rtx_camera_rays(self._h, C.byref(cam), width, height, len(xy), _ptr(xy), _ptr(out)))
         return out
+
+
+class MultiRenderer:
+    """Several GPUs of one node behind one handle (rtx_multi_*): scene and grid replicated, interleaved row tiles, rows
+    copied to the first GPU.  `devices`: list of device ids; an id may repeat (ranks then share that GPU)."""
+
+    def __init__(self, devices):
+        lib = _load()
+        ids = np.ascontiguousarray(devices, np.int32)
+        self._h = C.c_void_p()
+        _check(lib.rtx_multi_create(C.byref(self._h), _ptr(ids), len(ids)))
+        self.devices = list(int(d) for d in ids)
+        self.scene = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _load().rtx_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, scene):
+        v, keep = scene._view()
+        _check(_load().rtx_multi_set_scene(self._h, C.byref(v)))
+        self.scene = scene
+        return self
+
+    def build_grid(self, res=15, sub=0, flags=GRID_REFERENCE | GRID_NESTED):
+        r = (res, res, res) if np.isscalar(res) else tuple(res)
+        _check(_load().rtx_multi_build_grid(self._h, r[0], r[1], r[2], sub, flags))
+        gi = GridInfo()
+        _check(_load().rtx_multi_get_grid_info(self._h, C.byref(gi)))
+        return gi
+
+    def render(self, width=0, height=0, max_depth=5, search=SEARCH_NESTED, tile_rows=8, want_ids=True, camera=None,
+               eps_bias=SceneReader.epsilonBias, u8=False, **sched):
+        """(rgb[H,W,3] float32 -- or uint8 with u8=True --, ids[H,W] or None, stats summed over the GPUs)."""
+        sc = self.scene
+        W = width if width > 0 else sc.width
+        H = height if height > 0 else sc.height
+        cam = camera if camera is not None else sc._camera()
+        p = _params(W, H, max_depth, eps_bias, search, tile_rows, 0, 1, 0, **sched)
+        rgb = np.zeros((H, W, 3), np.uint8 if u8 else np.float32)
+        ids = np.full((H, W), -2, np.int32) if want_ids else None
+        st = RenderStats()
+        if u8:
+            _check(_load().rtx_multi_render_u8(self._h, C.byref(cam), C.byref(p), _ptr(rgb), ORDER_RGB, _ptr(ids), C.byref(st)))
+        else:
+            _check(_load().rtx_multi_render(self._h, C.byref(cam), C.byref(p), _ptr(rgb), _ptr(ids), C.byref(st)))
+        return rgb, ids, st
+
+    def render_device(self, d_rgb_ptr, d_ids_ptr, width, height, max_depth=5, search=SEARCH_NESTED, tile_rows=8, camera=None,
+                      eps_bias=SceneReader.epsilonBias, want_stats=False, **sched):
+        """The assembled frame left in device memory of the first listed GPU (raw pointers); complete on return."""
+        cam = camera if camera is not None else self.scene._camera()
+        p = _params(width, height, max_depth, eps_bias, search, tile_rows, 0, 1, 0, **sched)
+        st = RenderStats() if want_stats else None
+        _check(_load().rtx_multi_render_device(self._h, C.byref(cam), C.byref(p), C.c_void_p(d_rgb_ptr),
+                                               C.c_void_p(d_ids_ptr) if d_ids_ptr else None, C.byref(st) if st is not None else None))
+        return st
 
 
 def quantize(rgb):

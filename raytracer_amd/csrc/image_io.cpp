@@ -123,10 +123,15 @@ int rtx_save_image(const char* path, const float* rgb, int32_t w, int32_t h) {
         return RTX_E_NOMEM;
     }
     rtx_quantize(rgb, (int64_t)w * h * 3, q.data());
+    return rtx_save_image_u8(path, q.data(), w, h);
+}
+
+int rtx_save_image_u8(const char* path, const uint8_t* rgb8, int32_t w, int32_t h) {
+    if (!path || !rgb8 || w <= 0 || h <= 0) { rtx_set_error("rtx_save_image_u8: bad argument"); return RTX_E_INVALID; }
     std::string p(path);
     bool ppm = p.size() >= 4 && (p.compare(p.size() - 4, 4, ".ppm") == 0 || p.compare(p.size() - 4, 4, ".PPM") == 0);
     try {
-        return ppm ? write_ppm(path, q.data(), w, h) : write_png(path, q.data(), w, h);
+        return ppm ? write_ppm(path, rgb8, w, h) : write_png(path, rgb8, w, h);
     } catch (const std::bad_alloc&) {
         return RTX_E_NOMEM;
     }

@@ -161,6 +161,7 @@ struct rtx_ctx {
     float fine_pad = 0.0f;        // margin the nested lists were binned with
     DevBuf<float> rgb_local;
     DevBuf<int> ids_local;
+    DevBuf<unsigned char> rgb8_local;
     hipEvent_t ev[4 + 3 * 2 * RTX_MAX_LEVELS];
     bool have_events = false;
     // Set by a wave of the frame kernel that ran into the round limit: one int of pinned host memory the kernel
@@ -1035,8 +1036,11 @@ int rtx_render_device_noalloc(rtx_ctx* c, const rtx_camera* cam, const rtx_rende
     return render_frame(c, cam, p, d_rgb, d_ids, stream, nullptr, true);
 }
 
-int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* rgb_out, int32_t* prim_id_out, rtx_stats* stats) {
-    if (!c || !cam || !rgb_out) { rtx_set_error("rtx_render: null argument"); return RTX_E_INVALID; }
+// The pixel loop with the result on the host: floats (rgb_out) or, converted on the device first, bytes (rgb8_out).
+// This rank's rows arrive in the order rtx_local_rows() lists them; with one rank that is the image itself and one
+// copy moves it, otherwise every tile of rows is copied to its place in the caller's full-size image.
+static int render_to_host(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* rgb_out, uint8_t* rgb8_out, int32_t order,
+                          int32_t* prim_id_out, rtx_stats* stats) {
     int tile_rows, rank, world;
     int rc = check_params(p, &tile_rows, &rank, &world);
     if (rc) return rc;
@@ -1046,30 +1050,42 @@ int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, fl
     const size_t pixels = (size_t)nl * p->width;
     if ((rc = c->rgb_local.reserve(std::max(pixels, (size_t)1) * 3))) return rc;
     if (prim_id_out && (rc = c->ids_local.reserve(std::max(pixels, (size_t)1)))) return rc;
+    if (rgb8_out && (rc = c->rgb8_local.reserve(std::max(pixels, (size_t)1) * 3 + 16))) return rc;
     rtx_stats local_stats;
-    rc = rtx_render_device(c, cam, p, c->rgb_local.p, prim_id_out ? c->ids_local.p : nullptr, nullptr, stats ? stats : &local_stats);
+    rc = render_frame(c, cam, p, c->rgb_local.p, prim_id_out ? c->ids_local.p : nullptr, nullptr, stats ? stats : &local_stats, false);
     if (rc) return rc;
     if (nl == 0) return RTX_OK;
-    std::vector<int32_t> rows;
-    std::vector<float> rgb;
-    std::vector<int32_t> ids;
-    try {
-        rows.resize(nl);
-        rgb.resize(pixels * 3);
-        if (prim_id_out) ids.resize(pixels);
-    } catch (const std::bad_alloc&) {
-        return RTX_E_NOMEM;
+    if (rgb8_out) {
+        if ((rc = rtx_quantize_device(c, c->rgb_local.p, (int64_t)pixels, c->rgb8_local.p, order, nullptr))) return rc;
     }
-    int n_rows = 0;
-    rtx_local_rows(p, &n_rows, rows.data());
-    HIP_TRY(hipMemcpy(rgb.data(), c->rgb_local.p, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    if (prim_id_out) HIP_TRY(hipMemcpy(ids.data(), c->ids_local.p, pixels * sizeof(int), hipMemcpyDeviceToHost));
     const size_t W = (size_t)p->width;
-    for (int r = 0; r < nl; r++) {
-        memcpy(rgb_out + (size_t)rows[r] * W * 3, rgb.data() + (size_t)r * W * 3, W * 3 * sizeof(float));
-        if (prim_id_out) memcpy(prim_id_out + (size_t)rows[r] * W, ids.data() + (size_t)r * W, W * sizeof(int32_t));
+    const size_t px_bytes = rgb8_out ? 3 : 3 * sizeof(float);
+    const char* src = rgb8_out ? (const char*)c->rgb8_local.p : (const char*)c->rgb_local.p;
+    char* dst = rgb8_out ? (char*)rgb8_out : (char*)rgb_out;
+    const int n_tiles = (p->height + tile_rows - 1) / tile_rows;
+    size_t lr = 0;
+    for (int t = rank; t < n_tiles; t += world) {
+        // consecutive tiles of one rank are consecutive in the image only when it is the only rank
+        const size_t rows_here = world == 1 ? (size_t)p->height : (size_t)std::min(tile_rows, p->height - t * tile_rows);
+        const size_t y0 = (size_t)t * tile_rows;
+        HIP_TRY(hipMemcpy(dst + y0 * W * px_bytes, src + lr * W * px_bytes, rows_here * W * px_bytes, hipMemcpyDeviceToHost));
+        if (prim_id_out) HIP_TRY(hipMemcpy(prim_id_out + y0 * W, c->ids_local.p + lr * W, rows_here * W * sizeof(int32_t), hipMemcpyDeviceToHost));
+        lr += rows_here;
+        if (world == 1) break;
     }
     return RTX_OK;
+}
+
+int rtx_render(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, float* rgb_out, int32_t* prim_id_out, rtx_stats* stats) {
+    if (!c || !cam || !rgb_out) { rtx_set_error("rtx_render: null argument"); return RTX_E_INVALID; }
+    return render_to_host(c, cam, p, rgb_out, nullptr, RTX_ORDER_RGB, prim_id_out, stats);
+}
+
+int rtx_render_u8(rtx_ctx* c, const rtx_camera* cam, const rtx_render_params* p, uint8_t* rgb8_out, int32_t order, int32_t* prim_id_out,
+                  rtx_stats* stats) {
+    if (!c || !cam || !rgb8_out) { rtx_set_error("rtx_render_u8: null argument"); return RTX_E_INVALID; }
+    if (order != RTX_ORDER_RGB && order != RTX_ORDER_BGR) { rtx_set_error("rtx_render_u8: unknown channel order"); return RTX_E_INVALID; }
+    return render_to_host(c, cam, p, nullptr, rgb8_out, order, prim_id_out, stats);
 }
 
 int rtx_frame_status(rtx_ctx* c) {

@@ -14,7 +14,7 @@ from raytracer_amd import api
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "rtx.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rtx_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rtx_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():

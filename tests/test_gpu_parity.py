@@ -756,3 +756,66 @@ def test_frames_in_flight_on_their_own_streams_and_contexts():
     finally:
         for r, _, _, _ in slots:
             r.close()
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], [0] * 8, [0, 0, 0]])
+def test_several_gpus_behind_one_handle_reassemble_the_frame(renderer, devices):
+    """rtx_multi_*: scene and grid on every rank, interleaved row tiles, rows copied into the frame of the first GPU by
+    the library's own threads.  On this one-GPU machine the ranks share the card (a device id may repeat); the frame,
+    its id map, its 8-bit form and the ray counts must equal the single-context ones bit for bit."""
+    sr, _ = load(renderer, "scene6")
+    W, H = 200, 117
+    want, want_ids, st1 = renderer.render(W, H, 5)
+    m = rt.MultiRenderer(devices)
+    try:
+        m.set_scene(sr)
+        gi = m.build_grid(15, 0)
+        assert gi.n_refs == renderer.grid_info().n_refs and gi.sub == renderer.grid_info().sub
+        for tile_rows in (8, 5):
+            rgb, ids, st = m.render(W, H, 5, tile_rows=tile_rows)
+            assert np.array_equal(ids, want_ids) and np.array_equal(rgb.view(np.int32), want.view(np.int32)), (len(devices), tile_rows)
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (st1.primary_rays, st1.shadow_rays, st1.reflection_rays)
+            assert list(st.hits_per_level) == list(st1.hits_per_level)
+        rgb8, ids, _ = m.render(W, H, 5, u8=True)
+        assert np.array_equal(rgb8, rt.quantize(want)) and np.array_equal(ids, want_ids)
+        d = torch.full((H, W, 3), -1.0, device="cuda")
+        m.render_device(d.data_ptr(), 0, W, H, 5)
+        assert np.array_equal(d.cpu().numpy().view(np.int32), want.view(np.int32))
+        with pytest.raises(rt.RtxError):
+            m.render(W, H, 16)                                    # a rank's error comes back as a code, with its text
+    finally:
+        m.close()
+    with pytest.raises(rt.RtxError):
+        rt.MultiRenderer([0, 99])
+
+
+def test_eight_bit_frame_is_converted_on_the_device(renderer):
+    load(renderer, "scene4-specular")
+    want, want_ids, _ = renderer.render(333, 211, 5)
+    for bgr in (False, True):
+        rgb8, ids, st = renderer.render_u8(333, 211, 5, bgr=bgr, want_ids=True)
+        q = rt.quantize(want)
+        assert np.array_equal(rgb8, q[:, :, ::-1] if bgr else q) and np.array_equal(ids, want_ids) and st.primary_rays == 333 * 211
+
+
+def test_command_line_renderer_on_several_ranks(tmp_path):
+    """`rt --devices 0,0,0` (three ranks sharing this machine's GPU) and `rt --gpus 1` write the single-GPU image; the
+    constants the reference compiles in are options."""
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "bin", "rt")
+    scene = scene_path("scene6")
+    imgs = {}
+    for name, extra in (("one", []), ("gpus1", ["--gpus", "1"]), ("three", ["--devices", "0,0,0", "--headless"]),
+                        ("consts", ["--maxdepth", "5", "--grid", "15", "--bias", "0.001", "--frames", "2"]),
+                        ("depth0", ["--maxdepth", "0"])):
+        out = tmp_path / f"{name}.png"
+        res = subprocess.run([exe, scene, "--size", "160", "120", "--out", str(out)] + extra, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr
+        imgs[name] = np.asarray(Image.open(out).convert("RGB"))
+    for name in ("gpus1", "three", "consts"):
+        assert np.array_equal(imgs[name], imgs["one"]), name
+    assert not np.array_equal(imgs["depth0"], imgs["one"])
+    rgb_ref, _, _, _ = RefScene(scene).render(160, 120, 5)
+    assert (np.abs(imgs["one"].astype(int) - ref_quantize(rgb_ref).astype(int)) > 1).sum() == 0
