@@ -6,9 +6,13 @@ One "step" is one full frame: every rank renders its interleaved row tiles of th
 grid and all queues are resident in HBM before the timed region; the timed region is K frames between
 barrier + synchronize pairs, maximum over ranks.  Total work per step is fixed, so scaling is "strong".
 
+`value` is the throughput of a stream of frames: at every N, including N = 1, a few frames are in flight (each on its
+own HIP stream and device context), because the end of a frame is a handful of long chains of dependent rays that
+leave most of the GPU idle; `one_frame_at_a_time` holds the latency figure (one frame in flight, its gather completed
+before the next frame starts) at every N as well, so that a curve over N compares equals either way.
 Every timed frame is rendered as a first frame: the renderer's scheduling hint from the previous frame of the same
 camera (an ordering of the screen tiles, never a result) is switched off, because the reference renders one frame
-per process.  The rate with the hint is reported beside it (`with_previous_frame_hint`).  `value` counts the
+per process.  The rates with the hint are reported beside it (`with_previous_frame_hint`).  `value` counts the
 reference's rays (one camera ray per pixel, one shadow ray per light and one mirror ray per hit); camera rays that
 cannot meet any primitive are answered by a fill instead of a grid walk, so the rays that walked the grid and their
 rate are reported at top level too (`rays_walked`, `Mrays_walked_per_s`).
@@ -25,8 +29,9 @@ import time
 
 
 def _frames_in_flight(world, sync_gather):
-    """One rank renders one frame at a time; with more ranks several frames are in flight (see main())."""
-    return 1 if world == 1 or sync_gather else (3 if world < 8 else 6)
+    """Frames in flight of the throughput figure: enough to keep a GPU busy while the last paths of a frame drain --
+    three whole, half or quarter frames, six eighths of a frame (a rank's share shrinks with the number of ranks)."""
+    return 1 if sync_gather else (3 if world < 8 else 6)
 
 
 # Frames in flight run on separate HIP streams; a process gets 4 hardware queues by default and streams beyond that
@@ -93,7 +98,6 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-lists", action="store_true", help="skip the secondary reference-list measurement")
-    ap.add_argument("--no-frames-in-flight", action="store_true", help="skip the secondary two-frames-in-flight measurement")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline measurement and its roofline: no frames without the scheduling hint, no secondary "
                          "figures, no CPU baseline (what the committed rocprofv3 kernel trace is taken over, so that every "
@@ -104,13 +108,15 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true")
     ap.add_argument("--check-image", action="store_true", help="rank 0 also renders the whole frame alone and compares")
-    ap.add_argument("--sync-gather", action="store_true", help="complete every frame's gather before the next frame renders")
+    ap.add_argument("--sync-gather", "--one-frame-at-a-time", dest="sync_gather", action="store_true",
+                    help="one frame in flight: every frame is rendered, gathered and assembled before the next one starts "
+                         "(`value` then is the latency figure)")
     ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
                     help="what travels to rank 0: the float framebuffer (Image3f, the default) or the 8-bit image the "
                          "reference saves, converted on each GPU before the gather (a quarter of the bytes)")
     args = ap.parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_reference_lists = args.no_frames_in_flight = True
+        args.no_cpu_baseline = args.no_reference_lists = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,13 +148,13 @@ def main():
     gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
 
     as_u8 = args.gather == "u8"
-    # With more than one rank three to six frames are in flight, each on its own stream and device context.  A rank's share
-    # of a frame is small, its run time is set by the longest chains of dependent rays rather than by the amount of
-    # work; several frames side by side (each kernel launched with one or two workgroups per CU) fill the GPU, and the
-    # gather of a frame travels while the next ones render.  One rank renders one frame at a time.
-    # frames in flight and workgroups per CU of each frame's kernel.  An eighth of a frame takes 1.4 ms however many
-    # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (measured on one GPU,
-    # no gather: 0.33 ms per frame against 0.51 with three frames, 0.75 with two)
+    # Three to six frames are in flight, each on its own stream and device context.  The end of a frame -- and, with many
+    # ranks, all of a rank's small share of it -- is set by the longest chains of dependent rays rather than by the
+    # amount of work; several frames side by side (each kernel launched with one or two workgroups per CU) fill the GPU,
+    # and the gather of a frame travels while the next ones render.  Measured on one GPU: whole frames, scheduled as
+    # first frames, 2.73 ms one at a time, 2.18 two in flight, 2.14 three; an eighth of a frame takes 1.4 ms however many
+    # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (no gather: 0.33 ms per
+    # frame against 0.51 with three frames, 0.75 with two).
     depth = _frames_in_flight(world, args.sync_gather)
     wg_per_cu = 0 if depth == 1 else (2 if depth == 3 else 1)
     renderers = [r]
@@ -186,6 +192,19 @@ def main():
         streams[0].synchronize()
         return st, img
 
+    def timed(fn, n):
+        """Wall time of fn(n) between barrier + synchronize pairs, maximum over the ranks, in ms per frame."""
+        sync()
+        t0 = time.perf_counter()
+        fn(n)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_gather else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt / n * 1e3
+
     def frames(n, hint=False):
         """n frames back to back; a slot's exchange is completed when the slot is needed again."""
         for k in range(n):
@@ -206,38 +225,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # every slot's device context renders its first two frames here (its allocations, its first scheduling hint), so that
-    # the W warm-up frames and the timed ones meet the same state whichever slot they fall on
+    # every slot's device context renders its first two frames here (its allocations), so that the W warm-up frames and
+    # the timed ones meet the same state whichever slot they fall on
     for b in range(depth if depth > 1 else 0):
         with torch.cuda.stream(streams[b]):
             for _ in range(2):
                 render(b, wg=wg_per_cu)
     sync()
     frames(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    frames(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    # the same loop with the previous frame's scheduling hint (a camera that stands still or moves a little)
-    hinted_ms = None
+    ms_per_step = timed(frames, args.steps)
+    # latency: one frame at a time, each frame's gather completed before the next one starts
+    one_at_a_time = lambda n, hint=False: [frame(hint=hint) for _ in range(n)]
+    hinted_ms = latency_ms = latency_hinted_ms = None
     if not args.headline_only:
+        one_at_a_time(max(args.warmup, 1))
+        latency_ms = timed(one_at_a_time, args.steps)
+        # the same two loops with the previous frame's scheduling hint (a camera that stands still or moves a little)
         frames(max(args.warmup, 2), hint=True)
-        sync()
-        t0 = time.perf_counter()
-        frames(args.steps, hint=True)
-        sync()
-        hinted = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([hinted], dtype=torch.float64, device="cpu" if host_gather else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            hinted = float(t.item())
-        hinted_ms = hinted / args.steps * 1e3
+        hinted_ms = timed(lambda n: frames(n, hint=True), args.steps)
+        one_at_a_time(max(args.warmup, 2), hint=True)
+        latency_hinted_ms = timed(lambda n: one_at_a_time(n, hint=True), args.steps)
 
     # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames)
     st_count, _ = frame(want_stats=True, count=True)
@@ -269,7 +276,9 @@ def main():
         roofline = {
             "bound": "valu",
             "kernel": "k_frame (persistent: camera rays, coarse + nested 3D-DDA, triangle/sphere tests, shadow and mirror "
-                      "rays, Blinn-Phong, fold), 1 launch per frame, figures are per launch on rank 0",
+                      "rays, Blinn-Phong, fold), 1 launch per frame; figures are per launch on rank 0, the launch running "
+                      "alone on the GPU (first-frame schedule; HIP events on its stream, untimed frames after the timed loop)",
+            "achieved_in_timed_region": flops / (ms_per_step * 1e-3) / 1e12,
             "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "frac_of_packed_unfused_peak": achieved / PEAK_PACKED_UNFUSED_TFLOPS, "peak_packed_unfused": PEAK_PACKED_UNFUSED_TFLOPS,
             "frac_of_unfused_peak": achieved / PEAK_UNFUSED_TFLOPS, "peak_unfused": PEAK_UNFUSED_TFLOPS,
@@ -294,11 +303,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "rays_walked": walked_rays, "Mrays_walked_per_s": walked_rays / (ms_per_step * 1e-3) / 1e6,
+            "frames_in_flight": depth,
             "frame_schedule": "every timed frame is a first frame: no tile order from a previous frame",
+            "one_frame_at_a_time": None if latency_ms is None else {
+                "ms_per_frame": latency_ms, "value": total_rays / (latency_ms * 1e-3) / 1e6,
+                "Mrays_walked_per_s": walked_rays / (latency_ms * 1e-3) / 1e6,
+                "what": "latency figure: one frame in flight, rendered, gathered and assembled before the next one starts "
+                        "(first frames, as the headline)"},
             "with_previous_frame_hint": None if hinted_ms is None else {
                 "ms_per_step": hinted_ms, "value": total_rays / (hinted_ms * 1e-3) / 1e6,
                 "Mrays_walked_per_s": walked_rays / (hinted_ms * 1e-3) / 1e6,
-                "what": "the same loop with the screen tiles ordered by the path depths the previous frame of the same "
+                "one_frame_at_a_time_ms": latency_hinted_ms,
+                "what": "the same loops with the screen tiles ordered by the path depths the previous frame of the same "
                         "camera recorded (order only; every ray of every frame is traced)"},
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4)"),
             "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
@@ -327,31 +343,6 @@ def main():
             "frac_of_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "frac_of_unfused_peak": tf / (stt.trace_ms * 1e-3) / 1e12 / PEAK_UNFUSED_TFLOPS,
         }
-    # secondary figure: throughput with two frames in flight on one GPU (each frame complete and on its own stream and
-    # device context; the second frame's workgroups take over the CUs that the first frame's last paths leave idle)
-    if world == 1 and not args.no_frames_in_flight:
-        second = rt.Renderer(local_rank)
-        second.set_scene(sr)
-        second.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
-        pair = [(r, torch.cuda.Stream(), local[0]), (second, torch.cuda.Stream(), torch.empty_like(local[0]))]
-
-        def overlapped(n):
-            for k in range(n):
-                rr, stream, buf = pair[k % 2]
-                rr.render_device(buf.data_ptr(), 0, W, H, max_depth, search, args.tile_rows, 0, 1, stream=stream.cuda_stream,
-                                 workgroups_per_cu=4)
-        overlapped(2 * max(args.warmup, 1))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        overlapped(args.steps)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.steps * 1e3
-        same = bool(torch.equal(pair[0][2], pair[1][2]))
-        out["two_frames_in_flight"] = {
-            "what": "the same frames, the next one started while the last paths of the current one still run (not the headline: "
-                    "one frame at a time above)",
-            "ms_per_step": ms, "value": total_rays / (ms * 1e-3) / 1e6, "unit": "Mrays/s", "frames_identical": same}
-        second.close()
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.scene, W, H, max_depth, args.cpu_row_step // 2, args.cpu_row_step)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
