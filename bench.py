@@ -145,7 +145,9 @@ def main():
     sr = rt.SceneReader().readScene(args.scene)
     r = rt.Renderer(local_rank)
     r.set_scene(sr)
-    gi = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+    # the nested search needs the nested grid only; the reference's cell lists are built where they are searched
+    grid_flags = rt.GRID_NESTED if search == rt.SEARCH_NESTED else rt.GRID_REFERENCE
+    gi = r.build_grid(15, args.sub, grid_flags)
 
     as_u8 = args.gather == "u8"
     # Three to six frames are in flight, each on its own stream and device context.  The end of a frame -- and, with many
@@ -161,7 +163,7 @@ def main():
     for _ in range(1, depth):
         extra = rt.Renderer(local_rank)
         extra.set_scene(sr)
-        extra.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+        extra.build_grid(15, args.sub, grid_flags)
         renderers.append(extra)
     streams = [torch.cuda.current_stream()] if depth == 1 else [torch.cuda.Stream() for _ in range(depth)]
     fg = FrameGather(H, W, 3, args.tile_rows, rank, world, torch.device("cpu") if host_gather else dev,
@@ -326,12 +328,15 @@ def main():
                        "rays_per_frame": {"primary": rays[0], "shadow": rays[1], "reflection": rays[2], "total": total_rays,
                                           "primary_walked": rays[3], "primary_filled": rays[0] - rays[3]},
                        "kernel_ms_rank0": {"frame": kern[0], "k_frame": kern[1]},
-                       "grid": {"refs_reference_lists": gi.n_refs, "fine_cells": gi.n_fine_cells,
+                       "grid": {"fine_cells": gi.n_fine_cells, "occupied_fine_cells": gi.n_occupied_fine_cells,
                                 "refs_fine": gi.n_fine_refs, "build_ms": gi.build_ms}},
             "roofline": roofline,
         }
     # secondary figure: the reference's own workload (every primitive of every reference cell list tested)
     if not args.no_reference_lists and world == 1 and search == rt.SEARCH_NESTED:
+        gi_ref = r.build_grid(15, args.sub, rt.GRID_REFERENCE | rt.GRID_NESTED)
+        out["config"]["grid"]["refs_reference_lists"] = gi_ref.n_refs
+        out["config"]["grid"]["build_ms_with_reference_lists"] = gi_ref.build_ms
         stc, _ = frame(want_stats=True, count=True, mode=rt.SEARCH_REFERENCE_LISTS)
         stt, _ = frame(want_stats=True, mode=rt.SEARCH_REFERENCE_LISTS)
         tf = algorithmic_flops([a + b for a, b in zip(stc.trace_work, stc.shade_work)])

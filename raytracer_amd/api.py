@@ -541,7 +541,7 @@ def raytrace(scenefilename, width=0, height=0, max_depth=5, device=0, search=SEA
     r = Renderer(device)
     try:
         r.set_scene(sr)
-        r.build_grid(15, 0, GRID_REFERENCE | GRID_NESTED)
+        r.build_grid(15, 0, GRID_NESTED if search == SEARCH_NESTED else GRID_REFERENCE)
         rgb, _, st = r.render(width, height, max_depth, search, want_ids=False)
     finally:
         r.close()

@@ -85,22 +85,27 @@ int main(int argc, char** argv) {
     printf("Image %d %d\n", w, h);
 
     const bool multi = !devices.empty();
+    // each search needs its own structure only: the nested grid, or the reference's cell lists
+    const uint32_t grid_flags = search == RTX_SEARCH_NESTED ? RTX_GRID_NESTED : RTX_GRID_REFERENCE;
     rtx_ctx* ctx = nullptr;
     rtx_multi* many = nullptr;
     rtx_grid_info gi;
     if (multi) {
         if ((rc = rtx_multi_create(&many, devices.data(), (int32_t)devices.size()))) return fail("creating device contexts", rc);
         if ((rc = rtx_multi_set_scene(many, &view))) return fail("uploading scene", rc);
-        if ((rc = rtx_multi_build_grid(many, grid, grid, grid, sub, RTX_GRID_REFERENCE | RTX_GRID_NESTED))) return fail("building grid", rc);
+        if ((rc = rtx_multi_build_grid(many, grid, grid, grid, sub, grid_flags))) return fail("building grid", rc);
         rtx_multi_get_grid_info(many, &gi);
     } else {
         if ((rc = rtx_create(&ctx, device))) return fail("creating device context", rc);
         if ((rc = rtx_set_scene(ctx, &view))) return fail("uploading scene", rc);
-        if ((rc = rtx_build_grid(ctx, grid, grid, grid, sub, RTX_GRID_REFERENCE | RTX_GRID_NESTED))) return fail("building grid", rc);
+        if ((rc = rtx_build_grid(ctx, grid, grid, grid, sub, grid_flags))) return fail("building grid", rc);
         rtx_get_grid_info(ctx, &gi);
     }
-    printf("grid %d^3 (+ nested x%d): %lld / %lld references, built in %.2f ms%s\n", grid, gi.sub, (long long)gi.n_refs,
-           (long long)gi.n_fine_refs, gi.build_ms, multi ? " on every GPU" : "");
+    if (search == RTX_SEARCH_NESTED)
+        printf("grid %d^3 with %d^3 nested cells each: %lld references, built in %.2f ms%s\n", grid, gi.sub, (long long)gi.n_fine_refs,
+               gi.build_ms, multi ? " on every GPU" : "");
+    else
+        printf("grid %d^3: %lld references, built in %.2f ms%s\n", grid, (long long)gi.n_refs, gi.build_ms, multi ? " on every GPU" : "");
 
     // the saved image is 8 bits per channel (Image3f::save, src/Image3f.h:128-133): it is converted on the GPU and
     // only those bytes cross to the host

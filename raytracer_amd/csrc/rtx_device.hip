@@ -135,7 +135,7 @@ struct rtx_ctx {
     bool have_ref = false, have_nested = false;
     rtx_grid_info ginfo{};
     DevBuf<float> ref_box, tight_box, bounds;
-    DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp;
+    DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp, scan_tmp;
     DevBuf<unsigned char> cocc;
     DevBuf<unsigned> wmask, cocc_bits;
     DevBuf<int> wpop, wpre, ostart, ocell;
@@ -552,6 +552,17 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene_view* v) {
     return RTX_OK;
 }
 
+// exclusive prefix sum of n counts into start[0..n] (start[n] = total), on the default stream
+static int device_scan(rtx_ctx* c, int n, const int* count, int* start) {
+    const int n_strips = (n + RTX_SCAN_STRIP - 1) / RTX_SCAN_STRIP;
+    int rc;
+    if ((rc = c->scan_tmp.reserve((size_t)std::max(n_strips, 1)))) return rc;
+    if (n_strips > 0) hipLaunchKernelGGL(k_scan_strips, dim3(n_strips), dim3(1024), 0, 0, n, count, start, c->scan_tmp.p);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, 0, n_strips, c->scan_tmp.p, n, start);
+    if (n_strips > 1) hipLaunchKernelGGL(k_scan_offsets, dim3(n_strips), dim3(1024), 0, 0, n, (const int*)c->scan_tmp.p, start);
+    return RTX_OK;
+}
+
 // count -> scan -> scatter -> order, for one set of boxes and one resolution
 static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevBuf<int>& start, DevBuf<int>& ids, int64_t* n_refs) {
     const int n = c->n_prims;
@@ -568,7 +579,7 @@ static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevB
     if (n > 0)
         hipLaunchKernelGGL((k_bin<false>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)nullptr, (int*)nullptr, eg,
                            (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_cells, c->cell_tmp.p, start.p);
+    if ((rc = device_scan(c, n_cells, c->cell_tmp.p, start.p))) return rc;
     int total = 0;
     HIP_TRY(hipMemcpy(&total, start.p + n_cells, sizeof(int), hipMemcpyDeviceToHost));
     if (total < 0) { rtx_set_error("cell reference count overflowed 2^31"); return RTX_E_LIMIT; }
@@ -577,9 +588,15 @@ static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevB
     if (n > 0)
         hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p, eg,
                            (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
-    hipLaunchKernelGGL(k_sort_small, dim3((n_cells + 255) / 256), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
-    hipLaunchKernelGGL(k_sort_lds, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24);
-    hipLaunchKernelGGL(k_sort_large, dim3(n_cells), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, c->scratch_ids.p, RTX_SORT_LDS_MAX);
+    // the fill cursors are done with: the same array now collects the cells whose lists are too long for one lane
+    int* long_cells = c->cell_tmp.p;
+    int* n_long = c->cell_tmp.p + n_cells;
+    HIP_TRY(hipMemsetAsync(n_long, 0, sizeof(int), 0));
+    hipLaunchKernelGGL(k_sort_small, dim3((n_cells + 255) / 256), dim3(256), 0, 0, n_cells, (const int*)start.p, ids.p, 24, long_cells, n_long);
+    const int sort_blocks = std::min(n_cells, c->n_cus * 8);
+    hipLaunchKernelGGL(k_sort_lds, dim3(sort_blocks), dim3(256), 0, 0, (const int*)long_cells, (const int*)n_long, (const int*)start.p, ids.p);
+    hipLaunchKernelGGL(k_sort_large, dim3(sort_blocks), dim3(256), 0, 0, (const int*)long_cells, (const int*)n_long, (const int*)start.p, ids.p,
+                       c->scratch_ids.p);
     HIP_TRY(hipGetLastError());
     *n_refs = total;
     return RTX_OK;
@@ -671,7 +688,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
             (rc = c->wpre.reserve((size_t)n_words + 1)) || (rc = c->words.reserve((size_t)n_words)))
             return rc;
         hipLaunchKernelGGL(k_words, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, c->wmask.p, c->wpop.p);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, 0, n_words, (const int*)c->wpop.p, c->wpre.p);
+        if ((rc = device_scan(c, n_words, c->wpop.p, c->wpre.p))) return rc;
         int n_occ = 0;
         HIP_TRY(hipMemcpy(&n_occ, c->wpre.p + n_words, sizeof(int), hipMemcpyDeviceToHost));
         if ((rc = c->ostart.reserve((size_t)n_occ + 1)) || (rc = c->ocell.reserve((size_t)std::max(n_occ, 1)))) return rc;

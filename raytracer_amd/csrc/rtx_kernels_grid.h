@@ -163,39 +163,80 @@ __global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cur
             }
 }
 
-// Exclusive prefix sum over the cell counts, one workgroup walking the array in 1024-wide strips.
-// start has n + 1 entries; start[n] = total.
-__global__ __launch_bounds__(1024) void k_scan(int n, const int* count, int* start) {
-    __shared__ int buf[1024];
-    __shared__ int carry;
-    const int tid = (int)threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = i < n ? count[i] : 0;
-        buf[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int add = tid >= off ? buf[tid - off] : 0;
-            __syncthreads();
-            buf[tid] += add;
-            __syncthreads();
-        }
-        if (i < n) start[i] = carry + buf[tid] - v;
-        __syncthreads();
-        if (tid == 1023) carry += buf[1023];
-        __syncthreads();
+// Exclusive prefix sum over the cell counts in three launches: every workgroup scans its own strip of RTX_SCAN_STRIP
+// counts and leaves the strip's total; one workgroup turns the totals into strip offsets; every workgroup adds its
+// offset.  start has n + 1 entries; start[n] = total.  n <= 2^27 cells gives at most 2^15 strips, which the one
+// workgroup of the middle launch walks in 32 passes.
+#define RTX_SCAN_STRIP 4096                      // counts per workgroup: 1024 lanes x 4
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* buf, int* total) {
+    // inclusive scan of one value per lane over 1024 lanes: per wave with lane shuffles, then the 16 wave totals
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
     }
-    if (tid == 0) start[n] = carry;
+    if (lane == 63) buf[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < 16 ? buf[lane] : 0;
+        for (int off = 1; off < 16; off <<= 1) {
+            const int y = __shfl_up(w, off);
+            if (lane >= off) w += y;
+        }
+        if (lane < 16) buf[16 + lane] = w;           // inclusive totals of waves 0..lane
+    }
+    __syncthreads();
+    const int before = wave > 0 ? buf[16 + wave - 1] : 0;
+    *total = buf[31];
+    __syncthreads();
+    return before + x - v;
+}
+__global__ __launch_bounds__(1024) void k_scan_strips(int n, const int* count, int* start, int* strip_total) {
+    __shared__ int buf[32];
+    const int base = (int)blockIdx.x * RTX_SCAN_STRIP + 4 * (int)threadIdx.x;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = base + k < n ? count[base + k] : 0; sum += v[k]; }
+    int total;
+    int run = block_exclusive_scan_1024(sum, buf, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (base + k < n) start[base + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) strip_total[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_scan_totals(int n_strips, int* strip_total, int n, int* start) {
+    __shared__ int buf[32];
+    int carry = 0;
+    for (int base = 0; base < n_strips; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < n_strips ? strip_total[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_1024(v, buf, &total);
+        if (i < n_strips) strip_total[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) start[n] = carry;
+}
+__global__ __launch_bounds__(1024) void k_scan_offsets(int n, const int* strip_total, int* start) {
+    const int off = strip_total[blockIdx.x];
+    const int base = (int)blockIdx.x * RTX_SCAN_STRIP + 4 * (int)threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (base + k < n) start[base + k] += off;
 }
 
-// Put every cell's ids in ascending (= file) order.  Short lists: one lane per cell, insertion sort.
-__global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_len) {
+// Put every cell's ids in ascending (= file) order.  Short lists: one lane per cell, insertion sort; the cells with
+// longer lists are collected in `long_cells` (their number in *n_long) for the workgroup-per-cell kernels below, which
+// walk that list with a fixed number of workgroups instead of being launched once per cell of the grid.
+__global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_len, int* long_cells, int* n_long) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (c >= n_cells) return;
     const int b = start[c], e = start[c + 1];
-    if (e - b < 2 || e - b > max_len) return;
+    if (e - b > max_len) { long_cells[atomicAdd(n_long, 1)] = c; return; }
+    if (e - b < 2) return;
     for (int i = b + 1; i < e; i++) {
         const int v = ids[i];
         int j = i - 1;
@@ -206,12 +247,13 @@ __global__ void k_sort_small(int n_cells, const int* start, int* ids, int max_le
 // Medium lists (up to RTX_SORT_LDS_MAX ids): one workgroup per cell, bitonic network over an LDS copy padded to a
 // power of two with INT_MAX.
 #define RTX_SORT_LDS_MAX 16384
-__global__ __launch_bounds__(256) void k_sort_lds(int n_cells, const int* start, int* ids, int min_len) {
+__global__ __launch_bounds__(256) void k_sort_lds(const int* long_cells, const int* n_long, const int* start, int* ids) {
     __shared__ int buf[RTX_SORT_LDS_MAX];
-    const int c = (int)blockIdx.x;
-    if (c >= n_cells) return;
+  for (int at = (int)blockIdx.x; at < *n_long; at += (int)gridDim.x) {
+    const int c = long_cells[at];
     const int b = start[c], e = start[c + 1], len = e - b;
-    if (len <= min_len || len > RTX_SORT_LDS_MAX) return;      // uniform over the workgroup
+    if (len > RTX_SORT_LDS_MAX) continue;                      // uniform over the workgroup
+    __syncthreads();                                           // the previous cell's copy-out is complete
     int padded = 64;
     while (padded < len) padded <<= 1;
     for (int i = (int)threadIdx.x; i < padded; i += 256) buf[i] = i < len ? ids[b + i] : 0x7fffffff;
@@ -229,14 +271,15 @@ __global__ __launch_bounds__(256) void k_sort_lds(int n_cells, const int* start,
         }
     }
     for (int i = (int)threadIdx.x; i < len; i += 256) ids[b + i] = buf[i];
+  }
 }
 // Longer lists: ids within a cell are distinct, so an element's final position is the number of smaller elements
 // (rank sort through a scratch copy, quadratic: only for lists that do not fit the LDS sort).
-__global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* start, int* ids, int* scratch, int min_len) {
-    const int c = (int)blockIdx.x;
-    if (c >= n_cells) return;
+__global__ __launch_bounds__(256) void k_sort_large(const int* long_cells, const int* n_long, const int* start, int* ids, int* scratch) {
+  for (int at = (int)blockIdx.x; at < *n_long; at += (int)gridDim.x) {
+    const int c = long_cells[at];
     const int b = start[c], e = start[c + 1], len = e - b;
-    if (len <= min_len) return;
+    if (len <= RTX_SORT_LDS_MAX) continue;
     for (int i = (int)threadIdx.x; i < len; i += 256) scratch[b + i] = ids[b + i];
     __syncthreads();
     for (int i = (int)threadIdx.x; i < len; i += 256) {
@@ -245,6 +288,7 @@ __global__ __launch_bounds__(256) void k_sort_large(int n_cells, const int* star
         for (int j = 0; j < len; j++) rank += scratch[b + j] < v ? 1 : 0;
         ids[b + rank] = v;
     }
+  }
 }
 
 // Per-reference copies of the primitive records in list order (nested grid): frecs[3j..3j+2] = record of fids[j]
