@@ -175,7 +175,7 @@ typedef struct rtx_render_params {
                                       contexts gives each a share (e.g. 1) so that their kernels run side by side */
     /* tuning of the persistent frame kernel (results never depend on it); <= 0 selects the default */
     int32_t  walk_budget;          /* grid steps a lane may take per round (3)                              */
-    int32_t  ready_threshold;      /* lanes with a finished ray that trigger a state update (48)            */
+    int32_t  ready_threshold;      /* lanes with a finished ray that trigger a state update (56)            */
     int32_t  drain_eighths;        /* ... once no new pixels are left: that many eighths of the live lanes (2) */
     int32_t  reserved0;
     int64_t  round_limit;          /* rounds a wave of the frame kernel may run before the frame is abandoned with

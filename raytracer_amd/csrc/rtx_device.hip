@@ -897,7 +897,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     f.max_depth = p->max_depth;
     f.bias = p->eps_bias;
     f.walk_budget = p->walk_budget > 0 ? p->walk_budget : 3;
-    f.ready_threshold = p->ready_threshold > 0 ? std::min(p->ready_threshold, 64) : 48;
+    f.ready_threshold = p->ready_threshold > 0 ? std::min(p->ready_threshold, 64) : 56;
     f.drain_num = p->drain_eighths > 0 ? std::min(p->drain_eighths, 8) : 2;
     f.helpers = (p->flags & RTX_RENDER_NO_HELPERS) ? 0 : 1;
     f.round_limit = p->round_limit > 0 ? (long long)p->round_limit : derived_round_limit(c, f, p->max_depth);

@@ -76,12 +76,41 @@ __device__ __forceinline__ bool quotient_negative(float num, float den) {
 // a numerator's sign already decides a failing comparison (the common case); the accepted set is unchanged.
 // Split in two so that the wave-cooperative search can run the divisions of several batches together:
 // numerators + sign tests, then quotients + comparisons.  hit_triangle is the two in sequence.
+#ifndef RT_PACKED_DETS
+#define RT_PACKED_DETS 1
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool triangle_numerators(f3 A, f3 e1, f3 e2, f3 O, f3 D, float& nb, float& ng, float& nt, float& detA) {
     const f3 d = A - O;
+#if RT_PACKED_DETS
+    // The four determinants two at a time, each pair in the two halves of packed fp32 operations.  Every component is
+    // the same sequence of separately rounded multiplies, subtractions and additions as det3 -- term k is
+    // (a[k] * b[k+1]) * c[k+2] - (c[k] * b[k+1]) * a[k+2], the sum (t0 + t1) + t2 -- so the values are det3's bit for bit.
+    //   (detA, nt) = det3(e1, e2, c) for c = D and c = d;   (nb, ng) = (det3(d, e2, D), det3(e1, d, D))
+    const float a1[3] = {e1.x, e1.y, e1.z}, b2[3] = {e2.x, e2.y, e2.z}, dd[3] = {d.x, d.y, d.z}, DD[3] = {D.x, D.y, D.z};
+    v2f t1[3], t2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+        const v2f cD_d_k = {DD[k], dd[k]}, cD_d_k2 = {DD[k2], dd[k2]};
+        const float m = a1[k] * b2[k1];
+        const v2f p = (v2f){m, m} * cD_d_k2;
+        const v2f q = (cD_d_k * (v2f){b2[k1], b2[k1]}) * (v2f){a1[k2], a1[k2]};
+        t1[k] = p - q;
+        const v2f a_k = {dd[k], a1[k]}, b_k1 = {b2[k1], dd[k1]}, a_k2 = {dd[k2], a1[k2]};
+        const v2f p2 = (a_k * b_k1) * (v2f){DD[k2], DD[k2]};
+        const v2f q2 = ((v2f){DD[k], DD[k]} * b_k1) * a_k2;
+        t2[k] = p2 - q2;
+    }
+    const v2f s1 = (t1[0] + t1[1]) + t1[2], s2 = (t2[0] + t2[1]) + t2[2];
+    detA = s1.x; nt = s1.y;
+    nb = s2.x; ng = s2.y;
+#else
     detA = det3(e1, e2, D);
     nb = det3(d, e2, D);
     ng = det3(e1, d, D);
     nt = det3(e1, e2, d);
+#endif
     // t > 0 fails for every quotient that is negative, zero (either sign) or NaN
     if (((as_int(nt) ^ as_int(detA)) < 0) || nt == 0.0f) return false;
     if (quotient_negative(nb, detA) || quotient_negative(ng, detA)) return false;
