@@ -135,7 +135,7 @@ struct rtx_ctx {
     bool have_ref = false, have_nested = false;
     rtx_grid_info ginfo{};
     DevBuf<float> ref_box, tight_box, bounds;
-    DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp, scan_tmp;
+    DevBuf<int> cstart, cids, fstart, fids, scratch_ids, cell_tmp, scan_tmp, wide_prims;
     DevBuf<unsigned char> cocc;
     DevBuf<unsigned> wmask, cocc_bits;
     DevBuf<int> wpop, wpre, ostart, ocell;
@@ -576,18 +576,32 @@ static int build_lists(rtx_ctx* c, const BinParams& bp, const float* boxes, DevB
     const int pb = (n + 255) / 256;
     const bool exact = bp.sub > 0;   // nested grid: triangles are binned by their own extent, not their box
     const float* eg = exact ? c->geom.p : nullptr;
-    if (n > 0)
+    // primitives spanning many cells are set aside by each pass and binned by a workgroup each: [list, count] twice
+    if ((rc = c->wide_prims.reserve(2 * ((size_t)n + 1)))) return rc;
+    int* wide[2] = {c->wide_prims.p, c->wide_prims.p + n + 1};
+    HIP_TRY(hipMemsetAsync(wide[0] + n, 0, sizeof(int), 0));
+    HIP_TRY(hipMemsetAsync(wide[1] + n, 0, sizeof(int), 0));
+    const int wide_blocks = std::max(1, std::min(n, c->n_cus * 8));
+    if (n > 0) {
         hipLaunchKernelGGL((k_bin<false>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)nullptr, (int*)nullptr, eg,
-                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
+                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p, wide[0], wide[0] + n);
+        hipLaunchKernelGGL((k_bin_wide<false>), dim3(wide_blocks), dim3(256), 0, 0, (const int*)wide[0], (const int*)(wide[0] + n), bp, boxes,
+                           c->cell_tmp.p, (const int*)nullptr, (int*)nullptr, eg, (const int*)c->kind.p, (const int*)c->xform.p,
+                           (const float*)c->xfwd.p);
+    }
     if ((rc = device_scan(c, n_cells, c->cell_tmp.p, start.p))) return rc;
     int total = 0;
     HIP_TRY(hipMemcpy(&total, start.p + n_cells, sizeof(int), hipMemcpyDeviceToHost));
     if (total < 0) { rtx_set_error("cell reference count overflowed 2^31"); return RTX_E_LIMIT; }
     if ((rc = ids.reserve((size_t)std::max(total, 1))) || (rc = c->scratch_ids.reserve((size_t)std::max(total, 1)))) return rc;
     HIP_TRY(hipMemsetAsync(c->cell_tmp.p, 0, ((size_t)n_cells + 1) * sizeof(int), 0));
-    if (n > 0)
+    if (n > 0) {
         hipLaunchKernelGGL((k_bin<true>), dim3(pb), dim3(256), 0, 0, n, bp, boxes, c->cell_tmp.p, (const int*)start.p, ids.p, eg,
-                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p);
+                           (const int*)c->kind.p, (const int*)c->xform.p, (const float*)c->xfwd.p, wide[1], wide[1] + n);
+        hipLaunchKernelGGL((k_bin_wide<true>), dim3(wide_blocks), dim3(256), 0, 0, (const int*)wide[1], (const int*)(wide[1] + n), bp, boxes,
+                           c->cell_tmp.p, (const int*)start.p, ids.p, eg, (const int*)c->kind.p, (const int*)c->xform.p,
+                           (const float*)c->xfwd.p);
+    }
     // the fill cursors are done with: the same array now collects the cells whose lists are too long for one lane
     int* long_cells = c->cell_tmp.p;
     int* n_long = c->cell_tmp.p + n_cells;
@@ -666,7 +680,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
             if (n > 0)
                 hipLaunchKernelGGL((k_bin<false>), dim3((n + 255) / 256), dim3(256), 0, 0, n, cp, (const float*)c->tight_box.p, c->cell_tmp.p,
                                    (const int*)nullptr, (int*)nullptr, (const float*)nullptr, (const int*)c->kind.p, (const int*)c->xform.p,
-                                   (const float*)c->xfwd.p);
+                                   (const float*)c->xfwd.p, (int*)nullptr, (int*)nullptr);
             std::vector<int> counts((size_t)n_coarse);
             HIP_TRY(hipMemcpy(counts.data(), c->cell_tmp.p, counts.size() * sizeof(int), hipMemcpyDeviceToHost));
             long long refs = 0, occupied = 0;

@@ -123,44 +123,79 @@ __device__ __forceinline__ bool tri_box_overlap(f3 c, f3 h, f3 a, f3 b, f3 cc) {
 // pass 1 (FILL = false): count references per cell; pass 2 (FILL = true): scatter primitive ids,
 // Grid::placeIntoGrid (src/grid.h:76-88) for every primitive at once.  With geom != nullptr (nested grid only) a
 // triangle is referenced only by the cells of its box range that the triangle itself overlaps.
-template <bool FILL>
-__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids,
-                      const float* geom, const int* kind, const int* xform, const float* xfwd) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n) return;
+// One lane per primitive walks the primitive's cells when they are few; a primitive whose box spans more than
+// RTX_BIN_WIDE cells (a wall of a room spans the whole grid) is put on the `wide` list instead and k_bin_wide gives
+// it a whole workgroup, so that the build does not wait for the one lane that holds the largest primitive.
+#define RTX_BIN_WIDE 256
+struct BinPrim {
     int c0[3], c1[3];
-    cell_range(bp, boxes + 6 * i, c0, c1);
-    bool exact = false;
-    f3 wa = mk(0, 0, 0), wb = wa, wc = wa, cellsz = wa, half = wa;
-    if (geom != nullptr && kind[i] == RTX_PRIM_TRIANGLE && (c1[0] > c0[0] || c1[1] > c0[1] || c1[2] > c0[2])) {
+    bool exact;
+    f3 wa, wb, wc, cellsz, half;
+};
+__device__ __forceinline__ BinPrim bin_prim(int i, const BinParams& bp, const float* boxes, const float* geom, const int* kind, const int* xform,
+                                           const float* xfwd) {
+    BinPrim q;
+    cell_range(bp, boxes + 6 * i, q.c0, q.c1);
+    q.exact = false;
+    q.wa = q.wb = q.wc = q.cellsz = q.half = mk(0, 0, 0);
+    if (geom != nullptr && kind[i] == RTX_PRIM_TRIANGLE && (q.c1[0] > q.c0[0] || q.c1[1] > q.c0[1] || q.c1[2] > q.c0[2])) {
         const float* gp = geom + 9 * i;
         const float* m = xfwd + 16 * xform[i];
-        wa = mul_point(m, mk(gp[0], gp[1], gp[2]));
-        wb = mul_point(m, mk(gp[3], gp[4], gp[5]));
-        wc = mul_point(m, mk(gp[6], gp[7], gp[8]));
-        cellsz = mk(bp.size.x / bp.res.x, bp.size.y / bp.res.y, bp.size.z / bp.res.z);
-        half = mk(0.5f * cellsz.x + bp.pad, 0.5f * cellsz.y + bp.pad, 0.5f * cellsz.z + bp.pad);
-        exact = true;
+        q.wa = mul_point(m, mk(gp[0], gp[1], gp[2]));
+        q.wb = mul_point(m, mk(gp[3], gp[4], gp[5]));
+        q.wc = mul_point(m, mk(gp[6], gp[7], gp[8]));
+        q.cellsz = mk(bp.size.x / bp.res.x, bp.size.y / bp.res.y, bp.size.z / bp.res.z);
+        q.half = mk(0.5f * q.cellsz.x + bp.pad, 0.5f * q.cellsz.y + bp.pad, 0.5f * q.cellsz.z + bp.pad);
+        q.exact = true;
     }
-    for (int z = c0[2]; z <= c1[2]; z++)
-        for (int y = c0[1]; y <= c1[1]; y++)
-            for (int x = c0[0]; x <= c1[0]; x++) {
-                if (exact) {
-                    const f3 centre = mk(bp.lo.x + ((float)x + 0.5f) * cellsz.x, bp.lo.y + ((float)y + 0.5f) * cellsz.y,
-                                         bp.lo.z + ((float)z + 0.5f) * cellsz.z);
-                    if (!tri_box_overlap(centre, half, wa, wb, wc)) continue;
-                }
-                int cell;
-                if (bp.sub > 0) {
-                    const int cx = x / bp.sub, cy = y / bp.sub, cz = z / bp.sub;
-                    const int coarse = cx + (bp.rx / bp.sub) * (cy + (bp.ry / bp.sub) * cz);
-                    cell = coarse * bp.cpb + (x - cx * bp.sub) + bp.sub * ((y - cy * bp.sub) + bp.sub * (z - cz * bp.sub));
-                } else {
-                    cell = x + bp.rx * (y + bp.ry * z);
-                }
-                const int k = atomicAdd(count_or_cursor + cell, 1);
-                if (FILL) ids[start[cell] + k] = i;
-            }
+    return q;
+}
+template <bool FILL>
+__device__ __forceinline__ void bin_cell(int i, const BinParams& bp, const BinPrim& q, int x, int y, int z, int* count_or_cursor, const int* start,
+                                         int* ids) {
+    if (q.exact) {
+        const f3 centre = mk(bp.lo.x + ((float)x + 0.5f) * q.cellsz.x, bp.lo.y + ((float)y + 0.5f) * q.cellsz.y,
+                             bp.lo.z + ((float)z + 0.5f) * q.cellsz.z);
+        if (!tri_box_overlap(centre, q.half, q.wa, q.wb, q.wc)) return;
+    }
+    int cell;
+    if (bp.sub > 0) {
+        const int cx = x / bp.sub, cy = y / bp.sub, cz = z / bp.sub;
+        const int coarse = cx + (bp.rx / bp.sub) * (cy + (bp.ry / bp.sub) * cz);
+        cell = coarse * bp.cpb + (x - cx * bp.sub) + bp.sub * ((y - cy * bp.sub) + bp.sub * (z - cz * bp.sub));
+    } else {
+        cell = x + bp.rx * (y + bp.ry * z);
+    }
+    const int k = atomicAdd(count_or_cursor + cell, 1);
+    if (FILL) ids[start[cell] + k] = i;
+}
+template <bool FILL>
+__global__ void k_bin(int n, BinParams bp, const float* boxes, int* count_or_cursor, const int* start, int* ids,
+                      const float* geom, const int* kind, const int* xform, const float* xfwd, int* wide, int* n_wide) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const BinPrim q = bin_prim(i, bp, boxes, geom, kind, xform, xfwd);
+    const long long cells = (long long)(q.c1[0] - q.c0[0] + 1) * (q.c1[1] - q.c0[1] + 1) * (q.c1[2] - q.c0[2] + 1);
+    if (wide != nullptr && cells > RTX_BIN_WIDE) { wide[atomicAdd(n_wide, 1)] = i; return; }
+    for (int z = q.c0[2]; z <= q.c1[2]; z++)
+        for (int y = q.c0[1]; y <= q.c1[1]; y++)
+            for (int x = q.c0[0]; x <= q.c1[0]; x++) bin_cell<FILL>(i, bp, q, x, y, z, count_or_cursor, start, ids);
+}
+// the primitives k_bin put aside: a workgroup per primitive, its lanes striding over the primitive's cells
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_bin_wide(const int* wide, const int* n_wide, BinParams bp, const float* boxes, int* count_or_cursor,
+                                                  const int* start, int* ids, const float* geom, const int* kind, const int* xform,
+                                                  const float* xfwd) {
+    for (int at = (int)blockIdx.x; at < *n_wide; at += (int)gridDim.x) {
+        const int i = wide[at];
+        const BinPrim q = bin_prim(i, bp, boxes, geom, kind, xform, xfwd);
+        const int nx = q.c1[0] - q.c0[0] + 1, ny = q.c1[1] - q.c0[1] + 1, nz = q.c1[2] - q.c0[2] + 1;
+        const long long cells = (long long)nx * ny * nz;
+        for (long long j = (long long)threadIdx.x; j < cells; j += 256) {
+            const int x = q.c0[0] + (int)(j % nx), y = q.c0[1] + (int)((j / nx) % ny), z = q.c0[2] + (int)(j / ((long long)nx * ny));
+            bin_cell<FILL>(i, bp, q, x, y, z, count_or_cursor, start, ids);
+        }
+    }
 }
 
 // Exclusive prefix sum over the cell counts in three launches: every workgroup scans its own strip of RTX_SCAN_STRIP
