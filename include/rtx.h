@@ -159,6 +159,9 @@ int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, 
                                         occupied fine cell                                                        */
 #define RTX_RENDER_NO_HELPERS   32u  /* a path's own lane traces its shadow rays and its mirror ray one after the
                                         other, as trace() does (src/main.cpp:85-97)                               */
+#define RTX_RENDER_HELPERS_EARLY 256u /* lanes without a path take over the shadow rays of fresh hits from the start of
+                                        the frame ...                                                             */
+#define RTX_RENDER_HELPERS_LATE  512u /* ... or only once their wave can draw no new pixels; default: by frame size  */
 #define RTX_RENDER_WAVES_3      64u  /* force the build held to 168 registers (3 waves per SIMD) ...              */
 #define RTX_RENDER_WAVES_4     128u  /* ... or the one held to 128 (4 waves per SIMD); default: chosen by frame size */
 
@@ -177,7 +180,8 @@ typedef struct rtx_render_params {
     int32_t  walk_budget;          /* grid steps a lane may take per round (3)                              */
     int32_t  ready_threshold;      /* lanes with a finished ray that trigger a state update (56)            */
     int32_t  drain_eighths;        /* ... once no new pixels are left: that many eighths of the live lanes (2) */
-    int32_t  reserved0;
+    int32_t  path_lanes;           /* paths a wave carries at a time; its other lanes stay free for the shadow rays of
+                                      fresh hits from the start of the frame (default: 64, 48 or 32 by frame size) */
     int64_t  round_limit;          /* rounds a wave of the frame kernel may run before the frame is abandoned with
                                       RTX_E_LIMIT; <= 0 derives the bound from the frame (every ray the frame can
                                       hold times every step a ray can take: no valid frame reaches it)      */

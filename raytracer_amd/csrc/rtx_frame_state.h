@@ -42,7 +42,9 @@ struct DevFrame {
     int walk_budget;               // persistent kernel: walk steps a lane may take per round
     int ready_threshold;           // persistent kernel: lanes with a finished ray that trigger a state update
     int drain_num;                 // ... after the cursor is exhausted: that many eighths of the lanes still alive
-    int helpers;                   // persistent kernel: idle lanes of a draining wave trace the shadow rays of fresh hits
+    int helpers;                   // persistent kernel: lanes without a path trace the shadow rays of fresh hits (1: once
+                                   // the wave can draw no new pixels, 2: from the start)
+    int path_lanes;                // persistent kernel: paths a wave carries at a time (64, or fewer to keep helper lanes)
     long long round_limit;         // persistent kernel: rounds after which a wave abandons the frame
     int* abort_host;               // ... and says so here (device address of a word of pinned host memory)
     DevCamera cam;

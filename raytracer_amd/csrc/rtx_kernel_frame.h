@@ -58,10 +58,13 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     bool exhausted = false;
     const int n_items = f.tile_list ? 64 * __builtin_amdgcn_readfirstlane(f.counters[CNT_TILES]) : f.n_items0;
     // Helpers.  The shadow rays of a hit and the mirror ray that leaves it do not depend on each other, but one lane
-    // traces them one after the other.  Once the wave can draw no new pixels its idle lanes take over the shadow
-    // rays of fresh hits (hit record handed over through LDS), the path's own lane goes on with the mirror ray at
-    // once, and the chain of dependent rays of a depth-5 path shrinks from 12 to 7.  The helper writes the level's
-    // term into the path's slot; a path folds only when all its helpers have reported (pending_helpers).
+    // traces them one after the other.  A lane without a path -- idle, or freed in the same state update -- takes over
+    // the shadow rays of a fresh hit (hit record handed over through LDS), the path's own lane goes on with the mirror
+    // ray at once, and the chain of dependent rays of a depth-5 path shrinks from 12 to 7.  The helper writes the
+    // level's term into the path's slot; a path folds only when all its helpers have reported (outstanding).
+    // f.helpers = 1: only once the wave can draw no new pixels (a frame bound by throughput gains nothing from shorter
+    // chains before that, and a path that waits for its helper idles a lane); 2: from the start, lanes that become free
+    // serve fresh hits before they draw new pixels (a frame that is a few chains of dependent rays per lane).
     const bool helpers = f.helpers != 0;
     outstanding[wave][lane] = 0;
     long long rounds_left = f.round_limit;              // bounds the loop whatever happens (the host derives it from the frame)
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
         const bool walking = alive && w.state != 2;
         const bool finished = alive && w.state == 2 && phase >= 0;
         const bool waiting = alive && w.state == 2 && phase < 0;
-        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : __popcll(__ballot(!alive)));
+        // (a wave keeps at most f.path_lanes paths: lanes beyond that stay free for the shadow rays of fresh hits)
+        const int n_paths = __popcll(__ballot(pix >= 0));
+        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : max(0, min(__popcll(__ballot(!alive)), f.path_lanes - n_paths)));
         // once the cursor is exhausted the wave drains: with few paths left, waiting for a full batch of finished
         // rays would chain every path to the slowest ray of each generation
         const int n_alive = __popcll(__ballot(alive));
@@ -88,12 +93,11 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             f3 O = w.O, D = w.D;
             float tl = w.t_limit;
             const bool worker = pix <= -2;
-            bool path_end = false, lit = false, want_helper = false, has_helper = false, act = finished;
+            bool path_end = false, lit = false, want_helper = false;
             int top = -1, next_light = -1;
             if (waiting && atomicAdd(&outstanding[wave][lane], 0) == 0) {       // every helper has reported
                 path_end = true;
                 top = phase == -1 ? level : level - 1;
-                act = true;
             }
             if (finished) {
                 if (phase == 0) {
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         if (level == 0 && f.ids) f.ids[pix] = prim;
                         acc = mk(0, 0, 0);
                         // (helpers report through LDS: the few hits of the deep levels keep their shadow rays)
-                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && exhausted && level < RTX_LDS_LEVELS; } else lit = true;
+                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && (exhausted || f.helpers > 1) && level < RTX_LDS_LEVELS; } else lit = true;
                     }
                 } else {                                        // src/main.cpp:57-75
                     const int li = phase - 1;
@@ -128,9 +132,69 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     if (li + 1 < sc.n_lights) next_light = li + 1; else lit = true;
                 }
             }
-            // hand fresh hits to idle lanes: the k-th lane with a fresh hit is served by the k-th idle lane
-            if (helpers && exhausted) {
-                const unsigned long long req_mask = __ballot(want_helper), idle_mask = __ballot(!alive);
+            const auto mirror_ray = [&]() {                     // src/main.cpp:85-94
+                const f3 V = normalize3(-rayDir);
+                const f3 R = (2.0f * dot3(V, N) * N) - V;
+                O = P + f.bias * R;
+                rayDir = R;
+                D = normalize3(R);
+                tl = FLT_MAX;
+                level++;
+                phase = 0;
+                begin = true;
+            };
+            // a level whose lights are all evaluated: its term goes into the path's slot (src/main.cpp:97-102)
+            if (lit) {
+                const float* m = sc.mats + 16 * material;
+                const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
+                const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+                if (worker) {                                   // a helper reports to the path it worked for
+                    const int owner = -2 - pix;
+                    stack_lds[wave][level][owner] = rec;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    atomicSub(&outstanding[wave][owner], 1);
+                    pix = -1;
+                } else {
+                    if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level - RTX_LDS_LEVELS] = rec;
+                    if (level < f.max_depth) mirror_ray();
+                    else { path_end = true; top = level; }
+                }
+            }
+            // a path that ends folds its levels from the deepest up -- once every helper of it has reported
+            if (path_end && helpers && atomicAdd(&outstanding[wave][lane], 0) != 0) {
+                phase = top == level ? -1 : -2;
+                w.state = 2;
+                path_end = false;
+            }
+            if (path_end) {
+                f3 C = mk(0, 0, 0);
+                const auto fold = [&](const float4 s4) {
+                    const float* m = sc.mats + 16 * as_int(s4.w);
+                    C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
+                };
+                // one loop per address space: a pointer selected inside a single loop would turn every read into a
+                // flat load
+                for (int d = top; d >= RTX_LDS_LEVELS; d--) fold(stack_g[d - RTX_LDS_LEVELS]);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const __attribute__((address_space(3))) float* sl =
+                    (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
+                for (int d = min(top, RTX_LDS_LEVELS - 1); d >= 0; d--)
+                    fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
+                f.rgb[3 * pix] = C.x;
+                f.rgb[3 * pix + 1] = C.y;
+                f.rgb[3 * pix + 2] = C.z;
+                if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
+                if (COUNT) log_deepest = max(log_deepest, top + 1);
+                pix = -1;
+                phase = 0;
+            }
+            // hand fresh hits to lanes without a path (idle before, or freed just now): the k-th lane with a fresh hit is
+            // served by the k-th such lane, which traces the hit's shadow rays while the path's own lane goes on with the
+            // mirror ray at once
+            bool served = false;
+            if (helpers && (exhausted || f.helpers > 1)) {
+                const bool free_lane = pix == -1;
+                const unsigned long long req_mask = __ballot(want_helper), idle_mask = __ballot(free_lane);
                 const int n_match = min(__popcll(req_mask), __popcll(idle_mask));
                 if (n_match > 0) {
                     const unsigned long long below = (1ull << lane) - 1ull;
@@ -143,11 +207,11 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         l.cand_n[lane] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
                         l.owner_at[req_rank] = lane;
                         atomicAdd(&outstanding[wave][lane], 1);
-                        has_helper = true;
                         next_light = -1;
+                        served = true;
                     }
                     wave_lds_sync();
-                    if (!alive && idle_rank < n_match) {
+                    if (free_lane && idle_rank < n_match) {
                         const int from = l.owner_at[idle_rank];
                         const float4 a = l.ray_a[from], b = l.ray_b[from], c = l.cand_n[from];
                         P = mk(a.x, a.y, a.z); material = as_int(a.w);
@@ -157,92 +221,37 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         if (COUNT) log_tasks++;
                         acc = mk(0, 0, 0);
                         next_light = 0;
-                        act = true;
                     }
                     wave_lds_sync();
                 }
             }
-            if (act) {
-                if (lit && worker) {                            // a helper reports: the level's term goes into the path's slot
-                    const float* m = sc.mats + 16 * material;
-                    const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
-                    const int owner = -2 - pix;
-                    stack_lds[wave][level][owner] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    atomicSub(&outstanding[wave][owner], 1);
-                    pix = -1;
-                } else if (lit || has_helper) {                 // src/main.cpp:85-102
-                    if (lit) {
-                        const float* m = sc.mats + 16 * material;
-                        const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
-                        const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-                        if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level - RTX_LDS_LEVELS] = rec;
-                    }
-                    if (level < f.max_depth) {
-                        const f3 V = normalize3(-rayDir);
-                        const f3 R = (2.0f * dot3(V, N) * N) - V;
-                        O = P + f.bias * R;
-                        rayDir = R;
-                        D = normalize3(R);
-                        tl = FLT_MAX;
-                        level++;
-                        phase = 0;
-                        begin = true;
-                    } else {
-                        path_end = true;
-                        top = level;
-                    }
-                }
-                if (next_light >= 0) {
-                    const float* lt = sc.lights + 12 * next_light;
-                    const f3 lpos = mk(lt[1], lt[2], lt[3]);
-                    const bool point = (int)lt[0] == RTX_LIGHT_POINT;
-                    const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
-                    O = P + f.bias * L;
-                    D = L;
-                    tl = point ? dot3(lpos - P, L) : FLT_MAX;
-                    phase = 1 + next_light;
-                    begin = true;
-                }
-                if (path_end && helpers && atomicAdd(&outstanding[wave][lane], 0) != 0) {
-                    // a helper still traces shadow rays for this path: fold when it has reported
-                    phase = top == level ? -1 : -2;
-                    w.state = 2;
-                    path_end = false;
-                }
-                if (path_end) {
-                    f3 C = mk(0, 0, 0);
-                    const auto fold = [&](const float4 s4) {
-                        const float* m = sc.mats + 16 * as_int(s4.w);
-                        C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
-                    };
-                    // one loop per address space: a pointer selected inside a single loop would turn every read into a
-                    // flat load
-                    for (int d = top; d >= RTX_LDS_LEVELS; d--) fold(stack_g[d - RTX_LDS_LEVELS]);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const __attribute__((address_space(3))) float* sl =
-                        (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
-                    for (int d = min(top, RTX_LDS_LEVELS - 1); d >= 0; d--)
-                        fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
-                    f.rgb[3 * pix] = C.x;
-                    f.rgb[3 * pix + 1] = C.y;
-                    f.rgb[3 * pix + 2] = C.z;
-                    if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
-                    if (COUNT) log_deepest = max(log_deepest, top + 1);
-                    pix = -1;
-                    phase = 0;
-                }
+            if (served) {
+                if (level < f.max_depth) mirror_ray();
+                else { phase = -1; w.state = 2; }                // no mirror ray at the last level: wait for the helper, then fold
+            }
+            if (next_light >= 0) {                              // src/main.cpp:53-57,68-70
+                const float* lt = sc.lights + 12 * next_light;
+                const f3 lpos = mk(lt[1], lt[2], lt[3]);
+                const bool point = (int)lt[0] == RTX_LIGHT_POINT;
+                const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
+                O = P + f.bias * L;
+                D = L;
+                tl = point ? dot3(lpos - P, L) : FLT_MAX;
+                phase = 1 + next_light;
+                begin = true;
             }
             // lanes without a path draw the next pixels
             const bool idle = pix == -1;
             const unsigned long long idle_mask = __ballot(idle);
-            if (!exhausted && idle_mask != 0) {
-                const int n_idle = __popcll(idle_mask);
+            const int room = f.path_lanes - __popcll(__ballot(pix >= 0));
+            if (!exhausted && idle_mask != 0 && room > 0) {
+                const int n_idle = min(__popcll(idle_mask), room);
                 int base = 0;
                 if (lane == 0) base = atomicAdd(f.counters + CNT_TRACE_CUR, n_idle);
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (idle) {
-                    const int i = base + __popcll(idle_mask & ((1ull << lane) - 1ull));
+                const int idle_rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
+                if (idle && idle_rank < n_idle) {
+                    const int i = base + idle_rank;
                     if (i < n_items) {
                         const int blk = i >> 6, in = i & 63;
                         int lr, x;

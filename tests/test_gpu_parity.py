@@ -128,7 +128,7 @@ def test_scene7_4k_whole_frame_matches_the_oracle_golden(renderer, sub):
     W, H = int(g["width"]), int(g["height"])
     cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
     load(renderer, "scene7", sub)
-    for kw in (dict(tile_hint=False), dict(), dict(frame_waves=3), dict(tile_cull=False, helpers=False)):
+    for kw in (dict(tile_hint=False), dict(), dict(frame_waves=3), dict(tile_cull=False, helpers=False), dict(helpers="early", tile_hint=False)):
         rgb, ids, st = renderer.render(W, H, int(g["max_depth"]), rt.SEARCH_NESTED, **kw)
         assert np.array_equal(ids, g["ids"]), f"{int((ids != g['ids']).sum())} primary hit ids differ ({kw})"
         d = np.abs(rt.quantize(rgb).astype(np.int16) - g["rgb8"].astype(np.int16)).max(axis=2)
@@ -572,7 +572,7 @@ def test_both_register_budgets_of_the_frame_kernel(renderer, name, sub):
     for depth in (5, 9):
         want_rgb, want_ids, _ = renderer.render(W, H, depth, level_queues=True)
         for waves in (3, 4):
-            for helpers in (True, False):
+            for helpers in (True, False, "early", "late"):
                 for _ in range(2):                     # second frame: ordered by the first one's path depths
                     rgb, ids, _ = renderer.render(W, H, depth, frame_waves=waves, helpers=helpers)
                     assert np.array_equal(ids, want_ids), (depth, waves, helpers)
@@ -661,6 +661,8 @@ def _random_scene(rng, n_tris, n_spheres, n_lights):
 def test_random_scenes_match_the_oracle(renderer, tmp_path, seed):
     # frames this small would all run the frame kernel's three-wave build: odd seeds force the four-wave one
     waves = 4 if seed % 2 else 3
+    helpers = ("early", "late", True, False)[seed % 4]      # helper lanes from the start, while draining, by frame size, never
+    lanes = (0, 40, 17, 1)[(seed // 4) % 4]                 # paths per wave: by frame size, or forced
     rng = np.random.default_rng(1000 + seed)
     text = _random_scene(rng, int(rng.integers(0, 120)), int(rng.integers(0, 30)), int(rng.integers(0, 4)))
     path = tmp_path / "random.test"
@@ -672,7 +674,7 @@ def test_random_scenes_match_the_oracle(renderer, tmp_path, seed):
     for mode in MODES:
         for kw in PIPELINES.values():
             for _ in range(2):                       # the second frame runs with the first one's scheduling hint
-                rgb, ids, st = renderer.render(0, 0, depth, mode, frame_waves=waves, **kw)
+                rgb, ids, st = renderer.render(0, 0, depth, mode, frame_waves=waves, helpers=helpers, path_lanes=lanes, **kw)
                 assert_image_parity(rgb, ids, rgb_ref, ids_ref)
                 assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
                 assert st.traced_primary_rays + st.culled_pixels == st.primary_rays and st.traced_primary_rays >= int((ids_ref >= 0).sum())
