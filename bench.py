@@ -74,14 +74,18 @@ def cpu_baseline(scene_path, width, height, max_depth, row_start, row_step):
     _, _, _, cnt = counted.render(width, height, max_depth, row_start, row_step)
     counted.close()
     plain = ref_oracle.RefScene(scene_path, counting=False)
+    ref_oracle.set_schedule(True)                 # rows to threads as the reference's `#pragma omp parallel for` does
     _, _, sec, _ = plain.render(width, height, max_depth, row_start, row_step)
+    ref_oracle.set_schedule(False)
+    _, _, sec_dynamic, _ = plain.render(width, height, max_depth, row_start, row_step)
     plain.close()
     rays = cnt["primary"] + cnt["shadow"] + cnt["reflect"]
     n_rows = len(range(row_start, height, row_step))
     return {"value": rays / sec / 1e6, "unit": "Mrays/s", "cores": ref_oracle.threads(), "kind": "port",
             "sample": f"rows {row_start}::{row_step} ({n_rows} of {height} rows, {n_rows * width} pixels, {rays} rays) "
-                      f"of the same scene7 {width}x{height} depth-{max_depth} frame, OpenMP over rows, {sec:.2f} s",
-            "seconds": sec, "rays": rays}
+                      f"of the same scene7 {width}x{height} depth-{max_depth} frame, OpenMP over rows with the reference's "
+                      f"static schedule, {sec:.2f} s",
+            "seconds": sec, "rays": rays, "value_dynamic_schedule": rays / sec_dynamic / 1e6}
 
 
 def main():

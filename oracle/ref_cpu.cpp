@@ -459,6 +459,8 @@ V3 trace(V3 O, V3 D, Scene& sc, const float depth, int* first_prim) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
+static int g_reference_schedule = 0;      // see ref_set_schedule
+
 void* ref_load(const char* path, int use_grid) {
     Scene* s = new Scene;
     s->read(path, use_grid != 0);
@@ -573,6 +575,8 @@ void ref_camera_ray(void* h, int width, int height, int x, int y, float* out) {
 double ref_render(void* h, int width, int height, int max_depth, int row_start, int row_step,
                   float* rgb, int* ids, uint64_t* counters) {
     Scene* s = (Scene*)h;
+    if (g_reference_schedule) omp_set_schedule(omp_sched_static, 0);
+    else omp_set_schedule(omp_sched_dynamic, 1);
     if (width > 0) s->cam.width = width;
     if (height > 0) s->cam.height = height;
     const int W = s->cam.width, H = s->cam.height;
@@ -588,7 +592,7 @@ double ref_render(void* h, int width, int height, int max_depth, int row_start, 
 #ifdef REF_COUNT
         memset(&tl_cnt, 0, sizeof tl_cnt);
 #endif
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(runtime)
         for (int r = 0; r < nrows; r++) {
             int y = row_start + r * row_step;
             for (int x = 0; x < W; x++) {
@@ -636,5 +640,10 @@ int ref_has_counters() {
 }
 
 int ref_threads() { return omp_get_max_threads(); }
+
+// How ref_render hands the rows to the threads.  reference_schedule != 0: contiguous blocks of rows per thread, what the
+// reference's plain `#pragma omp parallel for` does (src/main.cpp:126; the timed CPU baseline uses this); 0: one row
+// at a time to whichever thread is free (the default here: same pixels, sooner, for the tests).
+void ref_set_schedule(int reference_schedule) { g_reference_schedule = reference_schedule; }
 
 }  // extern "C"

@@ -44,6 +44,7 @@ def _load(counting):
                                C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ref_quantize.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
     lib.ref_threads.restype = C.c_int
+    lib.ref_set_schedule.argtypes = [C.c_int]
     return lib
 
 
@@ -155,6 +156,13 @@ def quantize(rgb):
     out = np.zeros(rgb.shape, np.uint8)
     _lib().ref_quantize(_p(rgb), rgb.size, _p(out))
     return out
+
+
+def set_schedule(reference_schedule, counting=False):
+    """True: rows go to the threads in contiguous blocks, as the reference's plain `#pragma omp parallel for` hands them
+    out (src/main.cpp:126) -- what the timed CPU baseline uses; False (default): one row at a time to whichever thread is
+    free."""
+    _lib(counting).ref_set_schedule(1 if reference_schedule else 0)
 
 
 def threads():
