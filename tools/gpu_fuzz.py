@@ -38,11 +38,11 @@ with tempfile.TemporaryDirectory() as tmp:
             if not np.array_equal(want_ids, ids_ref) or np.abs(want_rgb - rgb_ref).max() > FLOAT_TOL:
                 problems.append(f"{mode_name}: levels vs oracle")
             for waves in (3, 4):
-                for helpers in (True, False):
+                for helpers, lanes in ((True, 0), (False, 0), ("early", 0), ("early", 24), ("early", 5), ("late", 0)):
                     for k in range(2):
-                        rgb, ids, st = r.render(0, 0, depth, mode, frame_waves=waves, helpers=helpers)
+                        rgb, ids, st = r.render(0, 0, depth, mode, frame_waves=waves, helpers=helpers, path_lanes=lanes)
                         if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
-                            problems.append(f"{mode_name}: frame waves={waves} helpers={helpers} pass={k}")
+                            problems.append(f"{mode_name}: frame waves={waves} helpers={helpers} lanes={lanes} pass={k}")
                         if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
                             problems.append(f"{mode_name}: ray counts waves={waves} helpers={helpers}")
         if problems:

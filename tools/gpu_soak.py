@@ -33,7 +33,9 @@ for name, sub, W, H, mode in cases:
     for waves in (3, 4):
         for k in range(n):
             got.fill_(-1.0)
-            r.render_device(got.data_ptr(), got_ids.data_ptr(), W, H, 5, mode, frame_waves=waves)
+            # every third frame with helper lanes from the start and a varying number of paths per wave
+            kw = dict(helpers="early", path_lanes=8 + (5 * k) % 56) if k % 3 == 2 else {}
+            r.render_device(got.data_ptr(), got_ids.data_ptr(), W, H, 5, mode, frame_waves=waves, tile_hint=k % 2 == 0, **kw)
             torch.cuda.synchronize()
             if not (torch.equal(got.view(torch.int32), want.view(torch.int32)) and torch.equal(got_ids, want_ids)):
                 differ += 1
