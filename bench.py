@@ -28,19 +28,23 @@ import time
 
 
 
-def _frames_in_flight(world, sync_gather):
+def _frames_in_flight(world, sync_gather, hw_queues):
     """Frames in flight of the throughput figure: enough to keep a GPU busy while the last paths of a frame drain --
-    three whole, half or quarter frames, six eighths of a frame (a rank's share shrinks with the number of ranks)."""
-    return 1 if sync_gather else (3 if world < 8 else 6)
+    three whole, half or quarter frames, six eighths of a frame (a rank's share shrinks with the number of ranks).  Six
+    streams need more than the four hardware queues a process gets by default: streams that share a queue run their
+    kernels one after the other (measured at 8 ranks: 0.37 ms per frame with 8 queues, 0.57 with 4 -- worse than three
+    frames of two workgroups per CU, 0.44), so with fewer than seven queues three frames it is."""
+    if sync_gather:
+        return 1
+    return 6 if world >= 8 and hw_queues >= 7 else 3
 
 
-# Frames in flight run on separate HIP streams; a process gets 4 hardware queues by default and streams beyond that
-# share one, which serialises their kernels.  Only a run that really keeps more than four frames in flight asks for
-# more, only when the operator has not set the variable, and before the HIP runtime starts; the effective value goes
-# into the JSON line.
-if (_frames_in_flight(int(os.environ.get("WORLD_SIZE", "1")), "--sync-gather" in sys.argv) > 4
-        and "GPU_MAX_HW_QUEUES" not in os.environ):
+# GPU_MAX_HW_QUEUES must be set before the HIP runtime starts.  A value the operator has set is left alone (and the
+# number of frames in flight follows it); only a run that wants six frames in flight and finds the variable unset asks
+# for eight.  The effective value goes into the JSON line.
+if int(os.environ.get("WORLD_SIZE", "1")) >= 8 and "--sync-gather" not in sys.argv and "GPU_MAX_HW_QUEUES" not in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
+HW_QUEUES = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
 
 import numpy as np
 import torch
@@ -161,7 +165,7 @@ def main():
     # first frames, 2.73 ms one at a time, 2.18 two in flight, 2.14 three; an eighth of a frame takes 1.4 ms however many
     # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (no gather: 0.33 ms per
     # frame against 0.51 with three frames, 0.75 with two).
-    depth = _frames_in_flight(world, args.sync_gather)
+    depth = _frames_in_flight(world, args.sync_gather, HW_QUEUES)
     wg_per_cu = 0 if depth == 1 else (2 if depth == 3 else 1)
     renderers = [r]
     for _ in range(1, depth):
