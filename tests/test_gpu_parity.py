@@ -824,3 +824,30 @@ def test_command_line_renderer_on_several_ranks(tmp_path):
     assert not np.array_equal(imgs["depth0"], imgs["one"])
     rgb_ref, _, _, _ = RefScene(scene).render(160, 120, 5)
     assert (np.abs(imgs["one"].astype(int) - ref_quantize(rgb_ref).astype(int)) > 1).sum() == 0
+
+
+def test_gather_over_rccl_on_a_side_stream_single_rank():
+    """The exchange step of the process-per-GPU path as bench.py issues it -- torch.distributed.gather, asynchronous,
+    from a side stream, on the "nccl" backend (RCCL) -- with the one rank a one-GPU machine allows: the call sequence,
+    stream ordering and completion are RCCL's, only the peers are missing."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "s = torch.cuda.Stream()\n"
+        "send = torch.zeros((270, 3840, 3), device=dev); recv = [torch.zeros_like(send)]\n"
+        "for k in range(3):\n"
+        "    with torch.cuda.stream(s):\n"
+        "        send.fill_(float(k + 1))\n"
+        "        work = dist.gather(send, recv, dst=0, async_op=True)\n"
+        "        work.wait()\n"
+        "        total = recv[0].sum()\n"
+        "    s.synchronize()\n"
+        "    assert float(total) == (k + 1) * send.numel(), float(total)\n"
+        "dist.destroy_process_group()\n"
+        "print('rccl gather ok')\n")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0 and "rccl gather ok" in res.stdout, res.stderr[-2000:]
