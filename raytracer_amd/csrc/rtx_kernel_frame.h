@@ -20,6 +20,12 @@
 //   3 waves (168 registers, 43.8 KB, record reads issued one batch ahead): shorter time per ray; the faster one when
 //     a frame is a few chains of dependent rays per lane (small images, a rank's share of a frame).
 // The host picks by the number of pixels of the traced window per resident lane.
+#ifndef RT_TAIL_SHARE
+#define RT_TAIL_SHARE 1
+#endif
+#ifndef RT_TAIL_MIN_LANES
+#define RT_TAIL_MIN_LANES 32
+#endif
 template <int WAVES>
 struct FrameBudget {
     static constexpr int lds_levels = WAVES >= 4 ? 5 : 6;   // path levels whose terms live in LDS (deeper: global)
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     // serve fresh hits before they draw new pixels (a frame that is a few chains of dependent rays per lane).
     const bool helpers = f.helpers != 0;
     outstanding[wave][lane] = 0;
+    int path_lanes = f.path_lanes;                      // paths this wave may carry at a time (wave-uniform)
     long long rounds_left = f.round_limit;              // bounds the loop whatever happens (the host derives it from the frame)
     int n_drawn = 0;                                    // pixels this lane drew
     // instrumented build: when the wave started, ran out of new pixels and ended (100 MHz clock), what it did
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
         const bool waiting = alive && w.state == 2 && phase < 0;
         // (a wave keeps at most f.path_lanes paths: lanes beyond that stay free for the shadow rays of fresh hits)
         const int n_paths = __popcll(__ballot(pix >= 0));
-        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : max(0, min(__popcll(__ballot(!alive)), f.path_lanes - n_paths)));
+        const int n_ready = __popcll(__ballot(finished)) + (exhausted ? 0 : max(0, min(__popcll(__ballot(!alive)), path_lanes - n_paths)));
         // once the cursor is exhausted the wave drains: with few paths left, waiting for a full batch of finished
         // rays would chain every path to the slowest ray of each generation
         const int n_alive = __popcll(__ballot(alive));
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                         if (level == 0 && f.ids) f.ids[pix] = prim;
                         acc = mk(0, 0, 0);
                         // (helpers report through LDS: the few hits of the deep levels keep their shadow rays)
-                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && (exhausted || f.helpers > 1) && level < RTX_LDS_LEVELS; } else lit = true;
+                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && (exhausted || f.helpers > 1 || path_lanes < 64) && level < RTX_LDS_LEVELS; } else lit = true;
                     }
                 } else {                                        // src/main.cpp:57-75
                     const int li = phase - 1;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             // served by the k-th such lane, which traces the hit's shadow rays while the path's own lane goes on with the
             // mirror ray at once
             bool served = false;
-            if (helpers && (exhausted || f.helpers > 1)) {
+            if (helpers && (exhausted || f.helpers > 1 || path_lanes < 64)) {
                 const bool free_lane = pix == -1;
                 const unsigned long long req_mask = __ballot(want_helper), idle_mask = __ballot(free_lane);
                 const int n_match = min(__popcll(req_mask), __popcll(idle_mask));
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             // lanes without a path draw the next pixels
             const bool idle = pix == -1;
             const unsigned long long idle_mask = __ballot(idle);
-            const int room = f.path_lanes - __popcll(__ballot(pix >= 0));
+            const int room = path_lanes - __popcll(__ballot(pix >= 0));
             if (!exhausted && idle_mask != 0 && room > 0) {
                 const int n_idle = min(__popcll(idle_mask), room);
                 int base = 0;
@@ -283,6 +290,14 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                 if (base + n_idle >= n_items) {
                     if (COUNT && !exhausted) log_exhausted = wall_clock64();
                     exhausted = true;
+                }
+                // The last pixels of the frame are shared out: once fewer are left than the launch has lanes, a wave
+                // only keeps its fair share of them as paths, so that the frame does not end on the few waves that
+                // happened to draw last -- and their other lanes are free for the shadow rays of those paths' hits.
+                if (RT_TAIL_SHARE) {
+                    const int left = max(n_items - (base + n_idle), 0);
+                    const int waves = (int)gridDim.x * (RTX_BLOCK / 64);
+                    path_lanes = min(f.path_lanes, max(left / waves + 1, RT_TAIL_MIN_LANES));
                 }
             }
             if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, xf, l, w, r, O, D, tl, wc);
