@@ -31,7 +31,6 @@ struct Rank {
     float* rows = nullptr;            // this rank's rows of the frame (device memory on its GPU)
     int32_t* row_ids = nullptr;
     size_t rows_cap = 0, ids_cap = 0; // floats / ints allocated
-    hipEvent_t done = nullptr;
     // worker
     std::thread thread;
     std::function<int()> job;
@@ -117,13 +116,14 @@ hipError_t copy_to_root(void* dst, int root, const void* src, int device, size_t
     return hipMemcpyPeerAsync(dst, root, src, device, bytes, stream);
 }
 
+// device buffer of the current device that only ever grows
 template <typename T>
-int grow(T** p, size_t* cap, size_t need, bool pinned_host) {
+int grow(T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return RTX_OK;
-    if (*p) { if (pinned_host) (void)hipHostFree(*p); else (void)hipFree(*p); }
+    if (*p) (void)hipFree(*p);
     *p = nullptr;
     *cap = 0;
-    const hipError_t e = pinned_host ? hipHostMalloc((void**)p, need * sizeof(T), hipHostMallocDefault) : hipMalloc((void**)p, need * sizeof(T));
+    const hipError_t e = hipMalloc((void**)p, need * sizeof(T));
     if (e != hipSuccess) { *p = nullptr; rtx_set_error("allocation of %zu bytes failed: %s", need * sizeof(T), hipGetErrorString(e)); return RTX_E_NOMEM; }
     *cap = need;
     return RTX_OK;
@@ -146,8 +146,8 @@ int render_into(rtx_multi* m, const rtx_camera* cam, const rtx_render_params* p,
             int rc = rtx_local_rows(&q, &n_rows, nullptr);
             if (rc) return rc;
             const size_t W = (size_t)q.width;
-            if ((rc = grow(&r.rows, &r.rows_cap, std::max<size_t>((size_t)n_rows * W * 3, 1), false))) return rc;
-            if (d_ids && (rc = grow(&r.row_ids, &r.ids_cap, std::max<size_t>((size_t)n_rows * W, 1), false))) return rc;
+            if ((rc = grow(&r.rows, &r.rows_cap, std::max<size_t>((size_t)n_rows * W * 3, 1)))) return rc;
+            if (d_ids && (rc = grow(&r.row_ids, &r.ids_cap, std::max<size_t>((size_t)n_rows * W, 1)))) return rc;
             memset(&r.stats, 0, sizeof r.stats);
             if (n_rows == 0) return RTX_OK;
             if ((rc = rtx_render_device(r.ctx, cam, &q, r.rows, d_ids ? r.row_ids : nullptr, r.stream, stats ? &r.stats : nullptr))) return rc;
@@ -204,9 +204,8 @@ int rtx_multi_create(rtx_multi** out, const int32_t* device_ids, int32_t n_devic
         r.device = device_ids[k];
         rc = rtx_create(&r.ctx, r.device);
         if (rc) break;
-        if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess) {
-            rtx_set_error("rtx_multi_create: stream / event creation on device %d failed", r.device);
+        if (hipSetDevice(r.device) != hipSuccess || hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) {
+            rtx_set_error("rtx_multi_create: stream creation on device %d failed", r.device);
             rc = RTX_E_DEVICE;
             break;
         }
@@ -236,7 +235,6 @@ void rtx_multi_destroy(rtx_multi* m) {
         if (!r.ctx) continue;                                     // creation stopped before this rank
         if (hipSetDevice(r.device) == hipSuccess) {
             if (r.stream) { (void)hipStreamSynchronize(r.stream); (void)hipStreamDestroy(r.stream); }
-            if (r.done) (void)hipEventDestroy(r.done);
             if (r.rows) (void)hipFree(r.rows);
             if (r.row_ids) (void)hipFree(r.row_ids);
         }
@@ -283,9 +281,9 @@ static int render_to_host(rtx_multi* m, const rtx_camera* cam, const rtx_render_
     const int root = m->ranks[0].device;
     if (hipSetDevice(root) != hipSuccess) { rtx_set_error("hipSetDevice(%d) failed", root); return RTX_E_DEVICE; }
     int rc;
-    if ((rc = grow(&m->d_frame, &m->frame_cap, pixels * 3, false))) return rc;
-    if (prim_id_out && (rc = grow(&m->d_frame_ids, &m->frame_ids_cap, pixels, false))) return rc;
-    if (rgb8_out && (rc = grow(&m->d_frame8, &m->frame8_cap, pixels * 3 + 16, false))) return rc;
+    if ((rc = grow(&m->d_frame, &m->frame_cap, pixels * 3))) return rc;
+    if (prim_id_out && (rc = grow(&m->d_frame_ids, &m->frame_ids_cap, pixels))) return rc;
+    if (rgb8_out && (rc = grow(&m->d_frame8, &m->frame8_cap, pixels * 3 + 16))) return rc;
     if ((rc = render_into(m, cam, p, m->d_frame, prim_id_out ? m->d_frame_ids : nullptr, stats))) return rc;
     if (hipSetDevice(root) != hipSuccess) { rtx_set_error("hipSetDevice(%d) failed", root); return RTX_E_DEVICE; }
     hipError_t e;
