@@ -723,6 +723,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         g.frx = frx; g.fry = fry; g.frz = frz;
         g.fcell = mk(g.size.x / (float)frx, g.size.y / (float)fry, g.size.z / (float)frz);
         g.inv_fcell = mk((float)frx / g.size.x, (float)fry / g.size.y, (float)frz / g.size.z);
+        g.fine_off = mk(-g.lo.x * g.inv_fcell.x, -g.lo.y * g.inv_fcell.y, -g.lo.z * g.inv_fcell.z);
         g.fstart = c->fstart.p;
         g.fids = c->fids.p;
         if ((rc = c->frecs.reserve(3 * (size_t)std::max<int64_t>(gi.n_fine_refs, 1)))) return rc;

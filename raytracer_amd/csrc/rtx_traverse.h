@@ -34,6 +34,7 @@ struct DevGrid {
     int cpb;                    // fine cells per coarse cell in the block-major numbering (sub^3 padded to 32)
     int frx, fry, frz;          // fine resolution = r * sub
     f3 fcell, inv_fcell;        // fine cell edge and its reciprocal
+    f3 fine_off;                // -lo * inv_fcell: fine coordinate of a point p = p * inv_fcell + fine_off
     const int* fstart;          // fine cell lists (tight padded boxes), CSR over cell = block * cpb + local,
                                 // block = coarse cell index, local = lx + sub * (ly + sub * lz)
     const int* fids;

@@ -186,9 +186,9 @@ struct Walker {
         lx += ax ? (D.x > 0 ? 1 : -1) : 0;
         ly += ay ? (D.y > 0 ? 1 : -1) : 0;
         lz += az ? (D.z > 0 ? 1 : -1) : 0;
-        fnx += ax ? fabsf(g.fcell.x * inv_d.x) : 0.0f;
-        fny += ay ? fabsf(g.fcell.y * inv_d.y) : 0.0f;
-        fnz += az ? fabsf(g.fcell.z * inv_d.z) : 0.0f;
+        fnx = ax ? __builtin_fmaf(g.fcell.x, fabsf(inv_d.x), fnx) : fnx;
+        fny = ay ? __builtin_fmaf(g.fcell.y, fabsf(inv_d.y), fny) : fny;
+        fnz = az ? __builtin_fmaf(g.fcell.z, fabsf(inv_d.z), fnz) : fnz;
         const bool outside = (unsigned)lx >= (unsigned)k || (unsigned)ly >= (unsigned)k || (unsigned)lz >= (unsigned)k;
         state = 1;
         if (done) { state = 2; hit = true; }
@@ -223,16 +223,19 @@ struct Walker {
                     state = 4;
                 } else if (occ.test(cell)) {
                     const int k = g.sub;
-                    const f3 p = O + fmaxf(t_in, 0.0f) * D;
+                    // (fused multiply-adds here: the fine walk only chooses which lists are looked at, and the margin the
+                    // lists were binned with is four orders of magnitude above its rounding)
+                    const float te = fmaxf(t_in, 0.0f);
+                    const f3 p = mk(__builtin_fmaf(te, D.x, O.x), __builtin_fmaf(te, D.y, O.y), __builtin_fmaf(te, D.z, O.z));
                     const int bx = __mul24(ix, k), by = __mul24(iy, k), bz = __mul24(iz, k);
-                    const int fx = min(max((int)floorf((p.x - g.lo.x) * g.inv_fcell.x) - bx, 0), k - 1);
-                    const int fy = min(max((int)floorf((p.y - g.lo.y) * g.inv_fcell.y) - by, 0), k - 1);
-                    const int fz = min(max((int)floorf((p.z - g.lo.z) * g.inv_fcell.z) - bz, 0), k - 1);
+                    const int fx = min(max((int)floorf(__builtin_fmaf(p.x, g.inv_fcell.x, g.fine_off.x)) - bx, 0), k - 1);
+                    const int fy = min(max((int)floorf(__builtin_fmaf(p.y, g.inv_fcell.y, g.fine_off.y)) - by, 0), k - 1);
+                    const int fz = min(max((int)floorf(__builtin_fmaf(p.z, g.inv_fcell.z, g.fine_off.z)) - bz, 0), k - 1);
                     lx = fx; ly = fy; lz = fz;
                     const float inf = __builtin_inff();
-                    const float px = g.lo.x + (float)(bx + fx + (D.x > 0 ? 1 : 0)) * g.fcell.x;
-                    const float py = g.lo.y + (float)(by + fy + (D.y > 0 ? 1 : 0)) * g.fcell.y;
-                    const float pz = g.lo.z + (float)(bz + fz + (D.z > 0 ? 1 : 0)) * g.fcell.z;
+                    const float px = __builtin_fmaf((float)(bx + fx + (D.x > 0 ? 1 : 0)), g.fcell.x, g.lo.x);
+                    const float py = __builtin_fmaf((float)(by + fy + (D.y > 0 ? 1 : 0)), g.fcell.y, g.lo.y);
+                    const float pz = __builtin_fmaf((float)(bz + fz + (D.z > 0 ? 1 : 0)), g.fcell.z, g.lo.z);
                     fnx = D.x != 0 ? (px - O.x) * inv_d.x : inf;
                     fny = D.y != 0 ? (py - O.y) * inv_d.y : inf;
                     fnz = D.z != 0 ? (pz - O.z) * inv_d.z : inf;
