@@ -31,6 +31,9 @@ struct FrameBudget {
     static constexpr int lds_levels = WAVES >= 4 ? 5 : 6;   // path levels whose terms live in LDS (deeper: global)
 };
 
+// layout of the first arguments of k_frame in its argument block
+struct FrameKernelArgs { DevScene sc; DevGrid g; DevSparse sp; DevFrame f; };
+
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
 __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int global_levels) {
     constexpr int RTX_LDS_LEVELS = FrameBudget<WAVES>::lds_levels;
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     __shared__ int outstanding[RTX_BLOCK / 64][64];   // per path lane: helpers that have not reported yet
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const Occupancy occ = stage_occupancy(g, occ_lds);
-    const XfRegs xf = load_xf_regs(sc.xinv, SINGLE_XF);
+    const XfRegs xf = {};                               // (the rounds need none: rays are transformed when they begin)
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
@@ -94,6 +97,17 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
         const int n_alive = __popcll(__ballot(alive));
         const int threshold = exhausted ? min(f.ready_threshold, max(1, (n_alive * f.drain_num) >> 3)) : f.ready_threshold;
         if (!__any(walking) || n_ready >= threshold) {
+            // What only the update reads of the frame, the scene and the grid is fetched from the kernel's argument
+            // block when an update runs (scalar loads) instead of living in scalar registers through the rounds: the
+            // kernel needs more scalar registers than there are, and what does not fit is kept in lanes of vector
+            // registers and moved back with vector instructions at every use (150 of them per update before this).
+            const __attribute__((address_space(4))) char* arg_block =
+                (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(arg_block));         // (keeps the loads inside the update)
+            const FrameKernelArgs& args = *(const FrameKernelArgs*)arg_block;
+            const DevFrame& fu = args.f;
+            const DevScene& su = args.sc;
+            const DevGrid& gu = args.g;
             if (COUNT) { wc.w_updates++; log_updates++; }
             const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
             bool begin = false;
@@ -111,22 +125,22 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     if (!w.hit) {                              // src/main.cpp:104-106
                         path_end = true;
                         top = level - 1;
-                        if (level == 0 && f.ids) f.ids[pix] = -1;
+                        if (level == 0 && fu.ids) fu.ids[pix] = -1;
                     } else {
                         if (COUNT) wc.nearest_hits++;
                         const int prim = r.best_prim;
-                        finish_hit(sc, prim, O, D, r.best_t, P, N, material);
+                        finish_hit(su, prim, O, D, r.best_t, P, N, material);
                         atomicAdd(&hit_count[wave][level], 1);
-                        if (level == 0 && f.ids) f.ids[pix] = prim;
+                        if (level == 0 && fu.ids) fu.ids[pix] = prim;
                         acc = mk(0, 0, 0);
                         // (helpers report through LDS: the few hits of the deep levels keep their shadow rays)
-                        if (sc.n_lights > 0) { next_light = 0; want_helper = helpers && (exhausted || f.helpers > 1 || path_lanes < 64) && level < RTX_LDS_LEVELS; } else lit = true;
+                        if (su.n_lights > 0) { next_light = 0; want_helper = helpers && (exhausted || f.helpers > 1 || path_lanes < 64) && level < RTX_LDS_LEVELS; } else lit = true;
                     }
                 } else {                                        // src/main.cpp:57-75
                     const int li = phase - 1;
                     if (!w.hit) {
-                        const float* lt = sc.lights + 12 * li;
-                        const float* m = sc.mats + 16 * material;
+                        const float* lt = su.lights + 12 * li;
+                        const float* m = su.mats + 16 * material;
                         if (COUNT) wc.light_evals++;
                         const f3 c = light_term(rayDir, D, N, mk(m[3], m[4], m[5]), mk(m[6], m[7], m[8]), m[12], mk(lt[4], lt[5], lt[6]));
                         if ((int)lt[0] == RTX_LIGHT_POINT) {
@@ -136,13 +150,13 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                             acc = acc + c;
                         }
                     }
-                    if (li + 1 < sc.n_lights) next_light = li + 1; else lit = true;
+                    if (li + 1 < su.n_lights) next_light = li + 1; else lit = true;
                 }
             }
             const auto mirror_ray = [&]() {                     // src/main.cpp:85-94
                 const f3 V = normalize3(-rayDir);
                 const f3 R = (2.0f * dot3(V, N) * N) - V;
-                O = P + f.bias * R;
+                O = P + fu.bias * R;
                 rayDir = R;
                 D = normalize3(R);
                 tl = FLT_MAX;
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             };
             // a level whose lights are all evaluated: its term goes into the path's slot (src/main.cpp:97-102)
             if (lit) {
-                const float* m = sc.mats + 16 * material;
+                const float* m = su.mats + 16 * material;
                 const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
                 const float4 rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
                 if (worker) {                                   // a helper reports to the path it worked for
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     pix = -1;
                 } else {
                     if (level < RTX_LDS_LEVELS) stack_lds[wave][level][lane] = rec; else stack_g[level - RTX_LDS_LEVELS] = rec;
-                    if (level < f.max_depth) mirror_ray();
+                    if (level < fu.max_depth) mirror_ray();
                     else { path_end = true; top = level; }
                 }
             }
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             if (path_end) {
                 f3 C = mk(0, 0, 0);
                 const auto fold = [&](const float4 s4) {
-                    const float* m = sc.mats + 16 * as_int(s4.w);
+                    const float* m = su.mats + 16 * as_int(s4.w);
                     C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
                 };
                 // one loop per address space: a pointer selected inside a single loop would turn every read into a
@@ -187,10 +201,10 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     (const __attribute__((address_space(3))) float*)&stack_lds[wave][0][lane];
                 for (int d = min(top, RTX_LDS_LEVELS - 1); d >= 0; d--)
                     fold(make_float4(sl[256 * d], sl[256 * d + 1], sl[256 * d + 2], sl[256 * d + 3]));
-                f.rgb[3 * pix] = C.x;
-                f.rgb[3 * pix + 1] = C.y;
-                f.rgb[3 * pix + 2] = C.z;
-                if (f.tile_cost && f.tile_cost[tslot] < top + 2) atomicMax(f.tile_cost + tslot, top + 2);
+                fu.rgb[3 * pix] = C.x;
+                fu.rgb[3 * pix + 1] = C.y;
+                fu.rgb[3 * pix + 2] = C.z;
+                if (fu.tile_cost && fu.tile_cost[tslot] < top + 2) atomicMax(fu.tile_cost + tslot, top + 2);
                 if (COUNT) log_deepest = max(log_deepest, top + 1);
                 pix = -1;
                 phase = 0;
@@ -233,15 +247,15 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                 }
             }
             if (served) {
-                if (level < f.max_depth) mirror_ray();
+                if (level < fu.max_depth) mirror_ray();
                 else { phase = -1; w.state = 2; }                // no mirror ray at the last level: wait for the helper, then fold
             }
             if (next_light >= 0) {                              // src/main.cpp:53-57,68-70
-                const float* lt = sc.lights + 12 * next_light;
+                const float* lt = su.lights + 12 * next_light;
                 const f3 lpos = mk(lt[1], lt[2], lt[3]);
                 const bool point = (int)lt[0] == RTX_LIGHT_POINT;
                 const f3 L = point ? normalize3(lpos - P) : normalize3(lpos);
-                O = P + f.bias * L;
+                O = P + fu.bias * L;
                 D = L;
                 tl = point ? dot3(lpos - P, L) : FLT_MAX;
                 phase = 1 + next_light;
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
             if (!exhausted && idle_mask != 0 && room > 0) {
                 const int n_idle = min(__popcll(idle_mask), room);
                 int base = 0;
-                if (lane == 0) base = atomicAdd(f.counters + CNT_TRACE_CUR, n_idle);
+                if (lane == 0) base = atomicAdd(fu.counters + CNT_TRACE_CUR, n_idle);
                 base = __builtin_amdgcn_readfirstlane(base);
                 const int idle_rank = __popcll(idle_mask & ((1ull << lane) - 1ull));
                 if (idle && idle_rank < n_idle) {
@@ -262,23 +276,23 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     if (i < n_items) {
                         const int blk = i >> 6, in = i & 63;
                         int lr, x;
-                        if (f.tile_list) {
-                            const int t = f.tile_list[blk];
+                        if (fu.tile_list) {
+                            const int t = fu.tile_list[blk];
                             lr = 8 * (t >> 16) + (in >> 3);
                             x = 8 * (t & 0xffff) + (in & 7);
-                            tslot = (t >> 16) * f.tbx + (t & 0xffff);
+                            tslot = (t >> 16) * fu.tbx + (t & 0xffff);
                         } else {
-                            lr = f.lr0 + 8 * (blk / f.nbx) + (in >> 3);
-                            x = 8 * (f.bx0 + blk % f.nbx) + (in & 7);
+                            lr = fu.lr0 + 8 * (blk / fu.nbx) + (in >> 3);
+                            x = 8 * (fu.bx0 + blk % fu.nbx) + (in & 7);
                         }
-                        if (lr < f.n_local_rows && x < f.W) {
-                            const int tile = lr / f.tile_rows;
-                            const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
-                            pix = lr * f.W + x;
+                        if (lr < fu.n_local_rows && x < fu.W) {
+                            const int tile = lr / fu.tile_rows;
+                            const int y = (fu.rank + tile * fu.world) * fu.tile_rows + (lr - tile * fu.tile_rows);
+                            pix = lr * fu.W + x;
                             n_drawn++;
                             if (COUNT) log_pixels++;
-                            O = f.cam.eye;
-                            rayDir = camera_ray(f.cam, x, y);
+                            O = fu.cam.eye;
+                            rayDir = camera_ray(fu.cam, x, y);
                             D = normalize3(rayDir);             // src/main.cpp:82
                             tl = FLT_MAX;
                             level = 0;
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     path_lanes = min(f.path_lanes, max(left / waves + 1, RT_TAIL_MIN_LANES));
                 }
             }
-            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(sc, g, xf, l, w, r, O, D, tl, wc);
+            if (begin) ray_begin<MODE, SINGLE_XF, COUNT>(su, gu, load_xf_regs(su.xinv, SINGLE_XF), l, w, r, O, D, tl, wc);
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             if (exhausted && !__any(pix != -1)) break;
         }
