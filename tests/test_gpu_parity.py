@@ -234,6 +234,17 @@ def test_ragged_image_sizes(renderer, w, h):
         assert_image_parity(rgb, ids, rgb_ref, ids_ref)
 
 
+@pytest.mark.parametrize("name,w,h", [("scene1", 7680, 4320), ("scene4-specular", 16384, 16), ("scene4-specular", 16, 8192)])
+def test_very_large_and_very_thin_frames(renderer, name, w, h):
+    """An 8K frame (33 M pixels, four times the benchmark's) and frames that are one or two tiles thin in either
+    direction, against the oracle: the tile map, the row split and the pixel indices at their extremes."""
+    load(renderer, name)
+    rgb_ref, ids_ref, _, cnt = RefScene(scene_path(name), counting=True).render(w, h, 5)
+    rgb, ids, st = renderer.render(w, h, 5, rt.SEARCH_NESTED)
+    assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+    assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+
+
 def test_camera_rays_bit_exact(renderer):
     load(renderer, "scene1")
     ref = RefScene(scene_path("scene1"))
