@@ -22,4 +22,5 @@ from .api import (  # noqa: F401
     quantize,
     raytrace,
     save_image,
+    save_image_u8,
 )

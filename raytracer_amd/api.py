@@ -516,6 +516,13 @@ def save_image(path, rgb):
     _check(_load().rtx_save_image(os.fsencode(path), _ptr(rgb), w, h))
 
 
+def save_image_u8(path, rgb8):
+    """Writes an 8-bit RGB image [h, w, 3] as PNG (or PPM by extension), as rtx_save_image does after its conversion."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    h, w = rgb8.shape[:2]
+    _check(_load().rtx_save_image_u8(os.fsencode(path), _ptr(rgb8), w, h))
+
+
 class Image3f:
     """Float RGB framebuffer with the reference's accessors (src/Image3f.h:23-60) and a save() without OpenCV."""
 

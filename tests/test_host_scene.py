@@ -169,6 +169,18 @@ def test_png_and_ppm_writers(tmp_path):
     assert tuple(np.asarray(Image.open(tmp_path / "b.png"))[2, 1]) == (127, 63, 255)
 
 
+@pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160), (5000, 3), (3, 5000)])
+def test_png_of_a_large_frame_is_compressed_in_bands_and_decodes_to_the_same_pixels(tmp_path, w, h):
+    """Frames above a megabyte are deflated as several bands of rows side by side, laid end to end in one stream."""
+    rng = np.random.default_rng(w + h)
+    img = np.zeros((h, w, 3), np.uint8)
+    img[h // 4: h // 2 + 1] = rng.integers(0, 256, (h // 2 + 1 - h // 4, w, 3), dtype=np.uint8)      # noise beside flat rows
+    img[:, w // 3] = 200
+    rt.save_image_u8(str(tmp_path / "big.png"), img)
+    back = np.asarray(Image.open(tmp_path / "big.png").convert("RGB"))
+    assert back.shape == img.shape and np.array_equal(back, img)
+
+
 @pytest.mark.parametrize("height,tile_rows,world", [(2160, 8, 8), (2160, 8, 1), (480, 8, 3), (23, 5, 4), (7, 8, 2), (1, 1, 1),
                                                     (100, 16, 7)])
 def test_row_split_is_a_partition(height, tile_rows, world):
