@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 static int fail(const char* what, int rc) {
@@ -24,7 +25,7 @@ static int fail(const char* what, int rc) {
 static void usage() {
     printf("usage: rt [scene.test] [--size W H] [--maxdepth N] [--grid R] [--sub K] [--bias E]\n"
            "          [--search nested|reference-lists] [--gpus N | --devices a,b,...] [--device D]\n"
-           "          [--out image.png|image.ppm] [--frames K] [--headless]\n"
+           "          [--out image.png|image.ppm] [--frames K] [--headless] [--timing]\n"
            "  --maxdepth N   recursion budget of trace() (reference: 5)\n"
            "  --grid R       cells per axis of the regular grid (reference: 15)\n"
            "  --sub K        fine cells per grid cell and axis of the nested search (0 = automatic)\n"
@@ -32,7 +33,8 @@ static void usage() {
            "  --gpus N       render on GPUs 0..N-1 (interleaved row tiles, gathered on GPU 0)\n"
            "  --devices ...  the same with an explicit device list (an id may repeat)\n"
            "  --frames K     render the frame K times and report the last one's time (warm-up for timing)\n"
-           "  --headless     accepted for compatibility: nothing is ever displayed\n");
+           "  --headless     accepted for compatibility: nothing is ever displayed\n"
+           "  --timing       print the wall time of every phase of the run\n");
 }
 
 int main(int argc, char** argv) {
@@ -40,6 +42,7 @@ int main(int argc, char** argv) {
     int width = 0, height = 0, max_depth = 5, device = 0, sub = 0, grid = 15, frames = 1;
     float bias = 0.001f;
     int search = RTX_SEARCH_NESTED;
+    bool timing = false;
     std::vector<int32_t> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -52,6 +55,7 @@ int main(int argc, char** argv) {
         else if (a == "--frames" && i + 1 < argc) frames = atoi(argv[++i]);
         else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
         else if (a == "--headless") {}
+        else if (a == "--timing") timing = true;
         else if (a == "--gpus" && i + 1 < argc) {
             const int n = atoi(argv[++i]);
             devices.clear();
@@ -69,11 +73,22 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "rt: unknown option %s\n", a.c_str()); return 2; }
     }
     if (frames < 1) frames = 1;
+    // --timing: milliseconds of wall time per phase of the process, printed at the end
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t_start = clock::now();
+    std::vector<std::pair<const char*, double>> phases;
+    clock::time_point t_phase = t_start;
+    const auto phase_done = [&](const char* name) {
+        const clock::time_point now = clock::now();
+        phases.emplace_back(name, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
 
     rtx_scene* scene = nullptr;
     int rc = rtx_scene_load(&scene, scene_path.c_str());
     if (rc) return fail("reading scene", rc);
     printf("reading in %s: \n", scene_path.c_str());
+    phase_done("parse");
     rtx_scene_view view;
     rtx_camera cam;
     int32_t w = 0, h = 0;
@@ -92,13 +107,19 @@ int main(int argc, char** argv) {
     rtx_grid_info gi;
     if (multi) {
         if ((rc = rtx_multi_create(&many, devices.data(), (int32_t)devices.size()))) return fail("creating device contexts", rc);
+        phase_done("device contexts (HIP start-up)");
         if ((rc = rtx_multi_set_scene(many, &view))) return fail("uploading scene", rc);
+        phase_done("scene upload");
         if ((rc = rtx_multi_build_grid(many, grid, grid, grid, sub, grid_flags))) return fail("building grid", rc);
+        phase_done("grid build");
         rtx_multi_get_grid_info(many, &gi);
     } else {
         if ((rc = rtx_create(&ctx, device))) return fail("creating device context", rc);
+        phase_done("device context (HIP start-up)");
         if ((rc = rtx_set_scene(ctx, &view))) return fail("uploading scene", rc);
+        phase_done("scene upload");
         if ((rc = rtx_build_grid(ctx, grid, grid, grid, sub, grid_flags))) return fail("building grid", rc);
+        phase_done("grid build");
         rtx_get_grid_info(ctx, &gi);
     }
     if (search == RTX_SEARCH_NESTED)
@@ -128,6 +149,7 @@ int main(int argc, char** argv) {
         auto t1 = std::chrono::high_resolution_clock::now();
         sec = std::chrono::duration<double>(t1 - t0).count();
     }
+    phase_done(frames > 1 ? "render + fetch (all frames)" : "render + fetch");
     const long long rays = (long long)(st.primary_rays + st.shadow_rays + st.reflection_rays);
     printf("finished raytracing after %g seconds (%s %.3f ms, %lld rays, %.1f Mrays/s%s)\n", sec,
            multi ? "slowest GPU's kernel" : "GPU frame", multi ? st.trace_ms : st.frame_ms, rays,
@@ -137,8 +159,15 @@ int main(int argc, char** argv) {
     if (out.empty()) out = "raytrace.png";
     if ((rc = rtx_save_image_u8(out.c_str(), rgb8.data(), w, h))) return fail("saving image", rc);
     printf("Written to: %s\n", out.c_str());
+    phase_done("image file");
     if (many) rtx_multi_destroy(many);
     if (ctx) rtx_destroy(ctx);
     rtx_scene_free(scene);
+    phase_done("teardown");
+    if (timing) {
+        printf("wall time per phase (ms):");
+        for (const auto& ph : phases) printf("  %s %.1f", ph.first, ph.second);
+        printf("  | total %.1f\n", std::chrono::duration<double, std::milli>(clock::now() - t_start).count());
+    }
     return 0;
 }
