@@ -129,7 +129,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                     } else {
                         if (COUNT) wc.nearest_hits++;
                         const int prim = r.best_prim;
-                        finish_hit(su, prim, O, D, r.best_t, P, N, material);
+                        finish_hit<SINGLE_XF, PRIMS>(su, prim, O, D, r.best_t, P, N, material);
                         atomicAdd(&hit_count[wave][level], 1);
                         if (level == 0 && fu.ids) fu.ids[pix] = prim;
                         acc = mk(0, 0, 0);

@@ -316,12 +316,15 @@ __device__ bool traverse(const DevScene& sc, const DevGrid& g, f3 O, f3 D, float
 // World-space position and normal of an accepted hit (Container::intersect, src/geometries.h:195-201):
 // P = O + t*D, N = normalize(transpose(inverse(M)) * (n, 0)) with n the object-space normal
 // (sphere: (O' + t*D') - S, :234,247; triangle: constant per triangle, :308).
+// SINGLE_XF: the scene has one transform (its matrix is then read through a wave-uniform address: scalar loads);
+// PRIMS: 1 = only triangles, 2 = only spheres in the scene (the other branch is compiled out), 0 = both
+template <bool SINGLE_XF = false, int PRIMS = 0>
 __device__ __forceinline__ void finish_hit(const DevScene& sc, int pid, f3 O, f3 D, float t, f3& P, f3& N, int& material) {
     const float4 q0 = sc.prims[3 * pid], q2 = sc.prims[3 * pid + 2];
-    const int xf = as_int(q2.y);
+    const int xf = SINGLE_XF ? 0 : as_int(q2.y);
     const float* m = sc.xinv + 16 * xf;
     f3 n;
-    if (as_int(q2.w) == RT_KIND_TRI) {
+    if (PRIMS == 1 || (PRIMS == 0 && as_int(q2.w) == RT_KIND_TRI)) {
         const float4 tn = sc.tri_normal[pid];
         n = mk(tn.x, tn.y, tn.z);
     } else {
