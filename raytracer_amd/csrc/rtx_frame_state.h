@@ -133,6 +133,15 @@ __device__ __forceinline__ f3 camera_ray(const DevCamera& c, int x, int y) {
 // evaluates exp2(y * log2(x)) in fp64 (atanh series for the logarithm, Taylor series for the exponential, both to
 // below 1e-16) and rounds once to fp32, which agrees with that except when the exact value lies within ~1e-13
 // relative of a rounding boundary.  Written out by hand because the general library pow needs ~40 more VGPRs.
+// A double constant held in scalar registers at the point of use.  The fp64 multiply-add takes no 64-bit literal, so
+// the compiler keeps every coefficient below in a vector register pair, loads them all ahead of the frame loop and,
+// short of registers there, parks them in scratch memory: 26 dependent scratch reads per evaluation.  Laundered
+// through an empty asm, a coefficient is two scalar moves next to the instruction that reads it.
+__device__ __forceinline__ double dconst(double c) {
+    unsigned lo = (unsigned)(unsigned long long)__double_as_longlong(c), hi = (unsigned)((unsigned long long)__double_as_longlong(c) >> 32);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ float pow_shine(float x, float y) {
     if (y == 0.0f || x == 1.0f) return 1.0f;
     if (x != x || y != y) return x + y;                        // NaN in, NaN out
@@ -143,19 +152,19 @@ __device__ __forceinline__ float pow_shine(float x, float y) {
     double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);   // [1, 2)
     if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
     const double s = (m - 1.0) / (m + 1.0), s2 = s * s;        // ln m = 2 atanh(s), |s| <= 0.1716
-    double p = 1.0 / 23.0;
-    p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
-    p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
-    p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0); p = fma(p, s2, 1.0);
-    const double log2x = fma(2.0 * s * p, 1.4426950408889634, (double)e);
+    double p = dconst(1.0 / 23.0);
+    p = fma(p, s2, dconst(1.0 / 21.0)); p = fma(p, s2, dconst(1.0 / 19.0)); p = fma(p, s2, dconst(1.0 / 17.0)); p = fma(p, s2, dconst(1.0 / 15.0));
+    p = fma(p, s2, dconst(1.0 / 13.0)); p = fma(p, s2, dconst(1.0 / 11.0)); p = fma(p, s2, dconst(1.0 / 9.0)); p = fma(p, s2, dconst(1.0 / 7.0));
+    p = fma(p, s2, dconst(1.0 / 5.0)); p = fma(p, s2, dconst(1.0 / 3.0)); p = fma(p, s2, 1.0);
+    const double log2x = fma(2.0 * s * p, dconst(1.4426950408889634), (double)e);
     const double z = (double)y * log2x;
     if (z < -160.0) return 0.0f;
     if (z > 130.0) return __builtin_inff();
-    const double n = rint(z), t = (z - n) * 0.6931471805599453;   // |t| <= 0.3466
-    double q = 1.0 / 6227020800.0;
-    q = fma(q, t, 1.0 / 479001600.0); q = fma(q, t, 1.0 / 39916800.0); q = fma(q, t, 1.0 / 3628800.0);
-    q = fma(q, t, 1.0 / 362880.0); q = fma(q, t, 1.0 / 40320.0); q = fma(q, t, 1.0 / 5040.0); q = fma(q, t, 1.0 / 720.0);
-    q = fma(q, t, 1.0 / 120.0); q = fma(q, t, 1.0 / 24.0); q = fma(q, t, 1.0 / 6.0); q = fma(q, t, 0.5);
+    const double n = rint(z), t = (z - n) * dconst(0.6931471805599453);   // |t| <= 0.3466
+    double q = dconst(1.0 / 6227020800.0);
+    q = fma(q, t, dconst(1.0 / 479001600.0)); q = fma(q, t, dconst(1.0 / 39916800.0)); q = fma(q, t, dconst(1.0 / 3628800.0));
+    q = fma(q, t, dconst(1.0 / 362880.0)); q = fma(q, t, dconst(1.0 / 40320.0)); q = fma(q, t, dconst(1.0 / 5040.0)); q = fma(q, t, dconst(1.0 / 720.0));
+    q = fma(q, t, dconst(1.0 / 120.0)); q = fma(q, t, dconst(1.0 / 24.0)); q = fma(q, t, dconst(1.0 / 6.0)); q = fma(q, t, 0.5);
     q = fma(q, t, 1.0); q = fma(q, t, 1.0);
     const double scale = __longlong_as_double((long long)((int)n + 1023) << 52);
     return (float)(q * scale);
