@@ -165,6 +165,10 @@ int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, 
 #define RTX_RENDER_WAVES_3      64u  /* force the build held to 168 registers (3 waves per SIMD) ...              */
 #define RTX_RENDER_WAVES_4     128u  /* ... or the one held to 128 (4 waves per SIMD); default: chosen by frame size */
 
+#define RTX_RENDER_GENERATIONS 1024u  /* generation pipeline: a wave traces 64 rays of one kind at a time (nearest-hit
+                                         rays, then the shadow rays of their hits) and keeps its paths in request
+                                         stacks in device memory, so that every state update runs on a full wave   */
+
 typedef struct rtx_render_params {
     int32_t  width, height;        /* full image; y = 0 is the top row (src/main.cpp:127-131)           */
     int32_t  max_depth;            /* recursion budget of trace(); the reference always passes 5 (:131)  */
@@ -185,6 +189,11 @@ typedef struct rtx_render_params {
     int64_t  round_limit;          /* rounds a wave of the frame kernel may run before the frame is abandoned with
                                       RTX_E_LIMIT; <= 0 derives the bound from the frame (every ray the frame can
                                       hold times every step a ray can take: no valid frame reaches it)      */
+    int32_t  endgame_eighths;      /* generation pipeline: pixels left per lane of the launch, in eighths, from which a
+                                      wave stops stocking up on paths and drains (both kinds of ray in one
+                                      generation): shortens the end of a frame that has the GPU to itself; < 0 = never;
+                                      0 selects the default (8 for a lone frame, never with workgroups_per_cu set) */
+    int32_t  reserved1;
 } rtx_render_params;
 
 typedef struct rtx_stats {

@@ -28,12 +28,13 @@ RENDER_WAVES_3 = 64
 RENDER_WAVES_4 = 128
 RENDER_HELPERS_EARLY = 256
 RENDER_HELPERS_LATE = 512
+RENDER_GENERATIONS = 1024
 
 # Scheduling and tuning fields of rtx_render_params applied to every render call of this process unless the call
 # names them itself.  The library reads no environment variables; development tools (tools/) fill this from theirs,
 # and the test suite sets a round limit here so that a kernel that never ends cannot hang the machine.
 DEFAULTS = dict(tile_hint=True, tile_cull=True, helpers=True, frame_waves=0, walk_budget=0, ready_threshold=0,
-                drain_eighths=0, path_lanes=0, round_limit=0)
+                drain_eighths=0, path_lanes=0, round_limit=0, generations=False, endgame_eighths=0)
 
 
 class RtxError(RuntimeError):
@@ -64,7 +65,8 @@ class _RenderParams(C.Structure):
                 ("search", C.c_int32), ("tile_rows", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
                 ("flags", C.c_uint32), ("workgroups_per_cu", C.c_int32),
                 ("walk_budget", C.c_int32), ("ready_threshold", C.c_int32), ("drain_eighths", C.c_int32),
-                ("path_lanes", C.c_int32), ("round_limit", C.c_int64)]
+                ("path_lanes", C.c_int32), ("round_limit", C.c_int64),
+                ("endgame_eighths", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -280,9 +282,11 @@ def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, 
     o = {k: (sched[k] if sched.get(k) is not None else v) for k, v in DEFAULTS.items()}
     flags |= ((0 if o["tile_hint"] else RENDER_NO_TILE_HINT) | (0 if o["tile_cull"] else RENDER_NO_TILE_CULL) |
               {0: RENDER_NO_HELPERS, 1: 0, True: 0, "late": RENDER_HELPERS_LATE, "early": RENDER_HELPERS_EARLY}[o["helpers"]] |
-              {0: 0, 3: RENDER_WAVES_3, 4: RENDER_WAVES_4}[int(o["frame_waves"])])
+              {0: 0, 3: RENDER_WAVES_3, 4: RENDER_WAVES_4}[int(o["frame_waves"])] |
+              (RENDER_GENERATIONS if o["generations"] else 0))
     return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu,
-                         int(o["walk_budget"]), int(o["ready_threshold"]), int(o["drain_eighths"]), int(o["path_lanes"]), int(o["round_limit"]))
+                         int(o["walk_budget"]), int(o["ready_threshold"]), int(o["drain_eighths"]), int(o["path_lanes"]), int(o["round_limit"]),
+                         int(o["endgame_eighths"]), 0)
 
 
 def local_rows(height, tile_rows=8, rank=0, world=1, width=1):

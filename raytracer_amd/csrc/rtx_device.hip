@@ -35,6 +35,9 @@ using namespace rt;
 // of the frame (48 paths below three times as many, when the launch has the GPU to itself)
 #define RTX_PIXELS_PER_LANE_FOR_EARLY_HELPERS 4.0
 
+// generation pipeline: default start of a lone frame's endgame, in eighths of a pixel left per lane of the launch
+#define RTX_GEN_ENDGAME_EIGHTHS 8
+
 #define RTX_MAX_LEVELS 16          // max_depth <= 15
 #define RTX_BLOCK 256
 
@@ -50,6 +53,7 @@ using namespace rt;
 #include "rtx_frame_state.h"
 #include "rtx_kernels_levels.h"
 #include "rtx_kernel_frame.h"
+#include "rtx_kernel_generations.h"
 #include "rtx_kernels_misc.h"
 #include "rtx_kernels_grid.h"
 
@@ -154,6 +158,7 @@ struct rtx_ctx {
     DevBuf<float4> hP, hN, hD, rO[2], rD[2], hL[RTX_MAX_LEVELS];
     DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
     DevBuf<float4> path_stack;
+    DevBuf<float4> gen_stacks;    // generation pipeline: the request stacks of every wave of the launch
     DevBuf<unsigned char> tile_map;
     DevBuf<signed char> tile_class;
     DevBuf<int> tile_list, tile_cost[2];
@@ -357,33 +362,39 @@ void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level
     if (timed) (void)hipEventRecord(ev[2], st);
 }
 
+// gen: the generation pipeline (k_frame_gen; `ps` = its request stacks, `levels` = path terms a request carries)
 template <int MODE, bool SINGLE_XF, int PRIMS, int WAVES>
-void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels) {
+void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, bool gen) {
+    if (gen) {
+        if (count) hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        else hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        return;
+    }
     if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
     else hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
 }
 
 template <int MODE, bool SINGLE_XF, int PRIMS>
-void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves) {
-    if (waves >= 4) launch_frame4<MODE, SINGLE_XF, PRIMS, 4>(c, sc, f, ps, blocks, st, count, levels);
-    else launch_frame4<MODE, SINGLE_XF, PRIMS, 3>(c, sc, f, ps, blocks, st, count, levels);
+void launch_frame3(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves, bool gen) {
+    if (waves >= 4) launch_frame4<MODE, SINGLE_XF, PRIMS, 4>(c, sc, f, ps, blocks, st, count, levels, gen);
+    else launch_frame4<MODE, SINGLE_XF, PRIMS, 3>(c, sc, f, ps, blocks, st, count, levels, gen);
 }
 
 // (`levels` = entries per lane of the strip `ps` of path terms kept in global memory; both builds index it from their
 // own first global level, so the strip sized for the four-wave build also serves the three-wave one)
 // picks the kernel specialisation for the scene: one transform or many, triangles only / spheres only / both
 template <int MODE>
-void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves) {
+void launch_frame(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, int waves, bool gen) {
     const bool single = c->n_xforms == 1;
     const int prims = c->n_spheres == 0 ? 1 : (c->n_triangles == 0 ? 2 : 0);
     if (single) {
-        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, ps, blocks, st, count, levels, waves);
-        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, ps, blocks, st, count, levels, waves);
-        else launch_frame3<MODE, true, 0>(c, sc, f, ps, blocks, st, count, levels, waves);
+        if (prims == 1) launch_frame3<MODE, true, 1>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
+        else if (prims == 2) launch_frame3<MODE, true, 2>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
+        else launch_frame3<MODE, true, 0>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
     } else {
-        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, ps, blocks, st, count, levels, waves);
-        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, ps, blocks, st, count, levels, waves);
-        else launch_frame3<MODE, false, 0>(c, sc, f, ps, blocks, st, count, levels, waves);
+        if (prims == 1) launch_frame3<MODE, false, 1>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
+        else if (prims == 2) launch_frame3<MODE, false, 2>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
+        else launch_frame3<MODE, false, 0>(c, sc, f, ps, blocks, st, count, levels, waves, gen);
     }
 }
 
@@ -809,6 +820,8 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     const size_t pixels = (size_t)nl * p->width;
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
+    const bool generations = !level_queues && (p->flags & RTX_RENDER_GENERATIONS) != 0;
+    const int gen_terms = std::max(p->max_depth, 1);   // path terms a request of the generation pipeline carries
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
     // path levels that do not fit the frame kernel's LDS strips (five levels in its four-wave build) live in global memory
@@ -817,8 +830,8 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     FrameScratch ws;
     HintState* hint = &c->hint;
     if (no_alloc) {
-        if (level_queues || (p->flags & RTX_RENDER_COUNT_WORK)) {
-            rtx_set_error("rtx_render_device_noalloc: the level-queue pipelines and the work counters need allocated workspace");
+        if (level_queues || generations || (p->flags & RTX_RENDER_COUNT_WORK)) {
+            rtx_set_error("rtx_render_device_noalloc: the level-queue and generation pipelines and the work counters need allocated workspace");
             return RTX_E_INVALID;
         }
         if (p->max_depth > RTX_NOALLOC_MAX_DEPTH || (long long)tbx * tby > RTX_NOALLOC_MAX_TILES) {
@@ -847,6 +860,9 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         // (instrumented frames log eight values per wave behind the 24 work counters)
         if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24 + 8 * (size_t)blocks * (RTX_BLOCK / 64))) ||
             (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * global_levels)))
+            return rc;
+        if (generations &&
+            (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * 2 * RTX_GEN_CAP * (RTX_GEN_HEADER + gen_terms))))
             return rc;
         ws.counters = c->counters.p;
         ws.work = c->work.p;
@@ -933,6 +949,13 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     if (p->flags & RTX_RENDER_HELPERS_LATE) f.helpers = 1;
     if (p->flags & RTX_RENDER_NO_HELPERS) f.helpers = 0;
     f.path_lanes = f.helpers == 2 ? path_lanes : 64;
+    {
+        // generation pipeline: a frame that has the GPU to itself ends sooner when its waves stop stocking up on paths
+        // toward the end; with several frames in flight the end of one frame overlaps the next and the denser
+        // generations win
+        const int eighths = p->endgame_eighths != 0 ? std::max(p->endgame_eighths, 0) : (p->workgroups_per_cu > 0 ? 0 : RTX_GEN_ENDGAME_EIGHTHS);
+        f.endgame_pixels = (int)std::min<long long>((long long)eighths * blocks * RTX_BLOCK / 8, 0x7fffffff);
+    }
     f.round_limit = p->round_limit > 0 ? (long long)p->round_limit : derived_round_limit(c, f, p->max_depth);
     f.abort_host = c->abort_dev;
     f.rgb = d_rgb;
@@ -1005,8 +1028,10 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     }
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
-        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, ws.path_stack, blocks, st, count, global_levels, frame_waves);
-        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, ws.path_stack, blocks, st, count, global_levels, frame_waves);
+        float4* const strips = generations ? c->gen_stacks.p : ws.path_stack;
+        const int n_levels = generations ? gen_terms : global_levels;
+        if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, strips, blocks, st, count, n_levels, frame_waves, generations);
+        else launch_frame<RT_SEARCH_NESTED>(c, sc, f, strips, blocks, st, count, n_levels, frame_waves, generations);
         HIP_TRY(hipEventRecord(ev[1], st));
     }
     for (int l = 0; level_queues && l < levels; l++) {

@@ -45,6 +45,7 @@ struct DevFrame {
     int helpers;                   // persistent kernel: lanes without a path trace the shadow rays of fresh hits (1: once
                                    // the wave can draw no new pixels, 2: from the start)
     int path_lanes;                // persistent kernel: paths a wave carries at a time (64, or fewer to keep helper lanes)
+    int endgame_pixels;            // generation pipeline: pixels left in the cursor from which a wave drains (0 = never)
     long long round_limit;         // persistent kernel: rounds after which a wave abandons the frame
     int* abort_host;               // ... and says so here (device address of a word of pinned host memory)
     DevCamera cam;

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 
 FLOAT_TOL = 1e-6          # absolute, on colours in [0, 1]
 MODES = [rt.SEARCH_REFERENCE_LISTS, rt.SEARCH_NESTED]
-# kernel pipelines: persistent per-wave path pools (default), level-synchronous global queues with the wave-cooperative
+# kernel pipelines: persistent per-wave path pools (default), the same kernel working in generations of one kind of ray
+# with its paths in request stacks in device memory, level-synchronous global queues with the wave-cooperative
 # traversal, and the same with one lane per ray
-PIPELINES = {"frame": {}, "levels": {"level_queues": True}, "serial": {"serial_lanes": True}}
+PIPELINES = {"frame": {}, "generations": {"generations": True}, "levels": {"level_queues": True}, "serial": {"serial_lanes": True}}
+PERSISTENT = ("frame", "generations")       # one launch per frame; camera rays through empty screen tiles are not walked
 GOLDEN_SCENES = ["scene1", "scene4-specular", "scene5", "scene6", "scene7"]
 
 
@@ -64,9 +66,9 @@ def test_render_matches_golden(renderer, name, mode, pipeline):
     # camera rays answered by a fill instead of a walk are reported, and only ones that hit nothing can be among them
     assert st.traced_primary_rays + st.culled_pixels == st.primary_rays
     assert st.culled_pixels <= int((g["ids"] < 0).sum()) and st.walked_rays == st.total_rays - st.culled_pixels
-    if pipeline != "frame":
+    if pipeline not in PERSISTENT:
         assert st.culled_pixels == 0
-    if pipeline == "frame" and mode == rt.SEARCH_NESTED:
+    if pipeline in PERSISTENT and mode == rt.SEARCH_NESTED:
         # camera rays through screen tiles that see no occupied fine cell are answered without walking the grid
         assert 0 < st.cell_steps <= cnt["cell_steps"]
     else:
@@ -103,7 +105,7 @@ def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
     rgb_r, ids_r, st_r = renderer.render(W, H, 5, rt.SEARCH_REFERENCE_LISTS)
     assert np.array_equal(ids_n, ids_r)
     assert np.array_equal(rgb_n.view(np.int32), rgb_r.view(np.int32))
-    for kw in (PIPELINES["levels"], PIPELINES["serial"]):        # every pipeline computes the same frame
+    for kw in (PIPELINES["levels"], PIPELINES["serial"], PIPELINES["generations"]):        # every pipeline computes the same frame
         rgb_l, ids_l, st_l = renderer.render(W, H, 5, rt.SEARCH_NESTED, **kw)
         assert np.array_equal(ids_l, ids_n) and np.array_equal(rgb_l.view(np.int32), rgb_n.view(np.int32))
         assert list(st_l.hits_per_level) == list(st_n.hits_per_level)
@@ -128,7 +130,9 @@ def test_scene7_4k_whole_frame_matches_the_oracle_golden(renderer, sub):
     W, H = int(g["width"]), int(g["height"])
     cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
     load(renderer, "scene7", sub)
-    for kw in (dict(tile_hint=False), dict(), dict(frame_waves=3), dict(tile_cull=False, helpers=False), dict(helpers="early", tile_hint=False)):
+    for kw in (dict(tile_hint=False), dict(), dict(frame_waves=3), dict(tile_cull=False, helpers=False), dict(helpers="early", tile_hint=False),
+               dict(generations=True, tile_hint=False), dict(generations=True), dict(generations=True, frame_waves=3, endgame_eighths=-1),
+               dict(generations=True, endgame_eighths=40)):
         rgb, ids, st = renderer.render(W, H, int(g["max_depth"]), rt.SEARCH_NESTED, **kw)
         assert np.array_equal(ids, g["ids"]), f"{int((ids != g['ids']).sum())} primary hit ids differ ({kw})"
         d = np.abs(rt.quantize(rgb).astype(np.int16) - g["rgb8"].astype(np.int16)).max(axis=2)
@@ -208,9 +212,13 @@ def test_round_limit_abandons_the_frame_with_an_error(renderer):
     torch.cuda.synchronize()
     with pytest.raises(rt.RtxError):                                               # the next call on the context reports it
         renderer.render_device(d_rgb.data_ptr(), 0, 160, 120, 5)
+    with pytest.raises(rt.RtxError) as e:                                          # the generation pipeline likewise
+        renderer.render(160, 120, 5, round_limit=3, generations=True)
+    assert e.value.code == -6
     rgb_ref, ids_ref, _, _ = RefScene(scene_path("scene6")).render(160, 120, 5)
-    rgb, ids, _ = renderer.render(160, 120, 5, round_limit=0)                      # derived limit: the whole frame
-    assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+    for kw in PIPELINES.values():
+        rgb, ids, _ = renderer.render(160, 120, 5, round_limit=0, **kw)            # derived limit: the whole frame
+        assert_image_parity(rgb, ids, rgb_ref, ids_ref)
 
 
 @pytest.mark.parametrize("depth", [0, 1, 3, 8, 15])
@@ -759,11 +767,11 @@ def test_frames_in_flight_on_their_own_streams_and_contexts():
                       torch.empty((H, W), dtype=torch.int32, device="cuda")))
     want = [slots[0][0].render(W, H, 5, camera=c) for c in cams]
     try:
-        for wg in (1, 2, 0, 64):
+        for wg, gen in ((1, False), (2, False), (0, False), (64, False), (2, True), (1, True)):
             for k in range(9):
                 r, s, d_rgb, d_ids = slots[k % 3]
                 r.render_device(d_rgb.data_ptr(), d_ids.data_ptr(), W, H, camera=cams[(k // 3) % 3], stream=s.cuda_stream,
-                                workgroups_per_cu=wg)
+                                workgroups_per_cu=wg, generations=gen)
                 if k % 3 == 2:                     # three frames are in flight: check them, then go on
                     torch.cuda.synchronize()
                     for r2, s2, rgb2, ids2 in slots:
