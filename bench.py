@@ -181,23 +181,24 @@ def main():
     staged = [torch.empty_like(fg.local_view(b), device=dev) if host_gather else fg.local_view(b) for b in range(depth)]
     local = [torch.empty(tuple(t.shape), dtype=torch.float32, device=dev) if as_u8 else t for t in staged]
 
-    def render(slot=0, want_stats=False, count=False, mode=search, wg=0, hint=False):
+    def render(slot=0, want_stats=False, count=False, mode=search, wg=0, hint=False, generations=None):
         """Enqueues this rank's rows of one frame on the slot's stream (the caller has made it current).  hint=False:
-        the frame is scheduled as a first frame (no tile order from the previous frame)."""
+        the frame is scheduled as a first frame (no tile order from the previous frame).  generations=None: the library
+        picks the pipeline of the persistent launch (by frame size, for launches that share the GPU)."""
         stream = streams[slot].cuda_stream
         rr = renderers[slot]
         st = rr.render_device(local[slot].data_ptr(), 0, W, H, max_depth, mode, args.tile_rows, rank, world, stream=stream,
-                              want_stats=want_stats, count_work=count, workgroups_per_cu=wg, tile_hint=hint)
+                              want_stats=want_stats, count_work=count, workgroups_per_cu=wg, tile_hint=hint, generations=generations)
         if as_u8:
             rr.quantize_device(local[slot].data_ptr(), local[slot].shape[0] * W, staged[slot].data_ptr(), stream=stream)
         if host_gather:
             fg.local_view(slot).copy_(staged[slot])
         return st
 
-    def frame(want_stats=False, count=False, mode=search, hint=False):
+    def frame(want_stats=False, count=False, mode=search, hint=False, generations=None):
         """One complete frame on slot 0: render, exchange, assemble (nothing left in flight)."""
         with torch.cuda.stream(streams[0]):
-            st = render(0, want_stats, count, mode, hint=hint)
+            st = render(0, want_stats, count, mode, hint=hint, generations=generations)
             img = fg.gather(0)
         streams[0].synchronize()
         return st, img
@@ -215,19 +216,29 @@ def main():
             dt = float(t.item())
         return dt / n * 1e3
 
+    launch_ms = []        # device time of every launch of the frame kernel in the last frames() call (rank 0's launches)
+
     def frames(n, hint=False):
-        """n frames back to back; a slot's exchange is completed when the slot is needed again."""
+        """n frames back to back; a slot's exchange is completed when the slot is needed again, and the device time of
+        the slot's finished frame kernel (the library's HIP events on the slot's stream) is read then."""
+        launch_ms.clear()
+        pending = [False] * depth
         for k in range(n):
             b = k % depth
             with torch.cuda.stream(streams[b]):
                 if fg.in_flight(b):
                     fg.finish(b)
+                if pending[b]:
+                    launch_ms.append(renderers[b].frame_times()[1])
                 render(b, wg=wg_per_cu, hint=hint)
+                pending[b] = True
                 fg.gather_async(b)
         for b in range(depth):
             with torch.cuda.stream(streams[b]):
                 if fg.in_flight(b):
                     fg.finish(b)
+                if pending[b]:
+                    launch_ms.append(renderers[b].frame_times()[1])
 
     def sync():
         torch.cuda.synchronize()
@@ -244,6 +255,7 @@ def main():
     sync()
     frames(args.warmup)
     ms_per_step = timed(frames, args.steps)
+    timed_launch_ms = list(launch_ms)
     # latency: one frame at a time, each frame's gather completed before the next one starts
     one_at_a_time = lambda n, hint=False: [frame(hint=hint) for _ in range(n)]
     hinted_ms = latency_ms = latency_hinted_ms = None
@@ -256,13 +268,19 @@ def main():
         one_at_a_time(max(args.warmup, 2), hint=True)
         latency_hinted_ms = timed(lambda n: one_at_a_time(n, hint=True), args.steps)
 
-    # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames)
-    st_count, _ = frame(want_stats=True, count=True)
-    # kernel time: HIP events around the frame kernel (on the stream it is launched on), mean over as many frames
-    # as were timed above
+    # which pipeline the timed launches ran (the library chooses by frame size for launches that share the GPU)
+    with torch.cuda.stream(streams[0]):
+        pipeline = render(0, want_stats=True, wg=wg_per_cu).pipeline
+    streams[0].synchronize()
+    gen = pipeline == 1
+    # ray counts, work counters and per-kernel times of this rank's share (separate, untimed frames, the timed launches'
+    # pipeline)
+    st_count, _ = frame(want_stats=True, count=True, generations=gen)
+    # the same kernel with the GPU to itself: HIP events around it (on the stream it is launched on), mean over as many
+    # frames as were timed above
     kern = []
     for _ in range(max(args.steps, 5)):
-        st_t, _ = frame(want_stats=True)
+        st_t, _ = frame(want_stats=True, generations=gen)
         kern.append((st_t.frame_ms, st_t.trace_ms, st_t.shade_ms, st_t.resolve_ms))
     kern = np.mean(np.array(kern), axis=0)
     rays_local = torch.tensor([st_count.primary_rays, st_count.shadow_rays, st_count.reflection_rays, st_count.traced_primary_rays],
@@ -280,19 +298,27 @@ def main():
         # its work counters come from the instrumented build of the same kernel on the same frame
         work = [a + b for a, b in zip(st_count.trace_work, st_count.shade_work)]
         flops = algorithmic_flops(work)
-        kernel_s = kern[1] * 1e-3
-        achieved = flops / kernel_s / 1e12
+        # Launches of the timed region: their mean device time (HIP events on each launch's own stream) and how many of
+        # them ran side by side on average (sum of their durations / length of the timed region).  One launch's rate is
+        # flops / avg_launch_ms; the GPU runs `launches_running_at_once` of them, so its rate over the timed region is
+        # the product, which equals flops * launches / time.  With one frame in flight the two are the same number.
+        avg_launch_ms = float(np.mean(timed_launch_ms)) if timed_launch_ms else kern[1]
+        at_once = float(np.sum(timed_launch_ms)) / (ms_per_step * args.steps) if timed_launch_ms else 1.0
+        achieved = flops / (avg_launch_ms * 1e-3) / 1e12 * at_once
+        achieved_alone = flops / (kern[1] * 1e-3) / 1e12
         frame_bytes = 12.0 * W * H / world
         roofline = {
             "bound": "valu",
-            "kernel": "k_frame (persistent: camera rays, coarse + nested 3D-DDA, triangle/sphere tests, shadow and mirror "
-                      "rays, Blinn-Phong, fold), 1 launch per frame; figures are per launch on rank 0, the launch running "
-                      "alone on the GPU (first-frame schedule; HIP events on its stream, untimed frames after the timed loop)",
-            "achieved_in_timed_region": flops / (ms_per_step * 1e-3) / 1e12,
+            "kernel": ("k_frame_gen" if gen else "k_frame") + " (persistent: camera rays, coarse + nested 3D-DDA, triangle/sphere "
+                      "tests, shadow and mirror rays, Blinn-Phong, fold), 1 launch per frame; figures are per launch on rank 0 "
+                      "over the timed region (first-frame schedule; the library's HIP events on each launch's stream)",
+            "avg_launch_ms": avg_launch_ms, "launches_timed": len(timed_launch_ms), "launches_running_at_once": at_once,
             "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
             "frac_of_packed_unfused_peak": achieved / PEAK_PACKED_UNFUSED_TFLOPS, "peak_packed_unfused": PEAK_PACKED_UNFUSED_TFLOPS,
             "frac_of_unfused_peak": achieved / PEAK_UNFUSED_TFLOPS, "peak_unfused": PEAK_UNFUSED_TFLOPS,
-            "algorithmic_flops_per_launch": flops, "avg_launch_ms": kern[1],
+            "alone": {"what": "the same kernel with the GPU to itself (one frame at a time, untimed frames after the timed loop)",
+                      "avg_launch_ms": kern[1], "achieved": achieved_alone, "frac": achieved_alone / PEAK_FP32_VALU_TFLOPS},
+            "algorithmic_flops_per_launch": flops,
             "work_per_launch": dict(zip(("tri_tests", "sphere_tests", "xform_evals", "cell_steps", "fine_steps",
                                          "light_evals", "nearest_hits", "rays"), (int(v) for v in work))),
             "hbm_algorithmic_GBs": frame_bytes / (kern[0] * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
@@ -314,6 +340,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "rays_walked": walked_rays, "Mrays_walked_per_s": walked_rays / (ms_per_step * 1e-3) / 1e6,
             "frames_in_flight": depth,
+            "pipeline": "generations of one kind of ray (k_frame_gen)" if gen else "per-lane paths (k_frame)",
             "frame_schedule": "every timed frame is a first frame: no tile order from a previous frame",
             "one_frame_at_a_time": None if latency_ms is None else {
                 "ms_per_frame": latency_ms, "value": total_rays / (latency_ms * 1e-3) / 1e6,

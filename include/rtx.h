@@ -167,7 +167,9 @@ int  rtx_download_grid(const rtx_ctx* ctx, uint32_t which, int32_t* cell_start, 
 
 #define RTX_RENDER_GENERATIONS 1024u  /* generation pipeline: a wave traces 64 rays of one kind at a time (nearest-hit
                                          rays, then the shadow rays of their hits) and keeps its paths in request
-                                         stacks in device memory, so that every state update runs on a full wave   */
+                                         stacks in device memory, so that every state update runs on a full wave ... */
+#define RTX_RENDER_NO_GENERATIONS 2048u /* ... or never; default: chosen by frame size for launches that share the GPU
+                                         with other frames (workgroups_per_cu given), off for a lone frame          */
 
 typedef struct rtx_render_params {
     int32_t  width, height;        /* full image; y = 0 is the top row (src/main.cpp:127-131)           */
@@ -213,7 +215,8 @@ typedef struct rtx_stats {
                                                  kernel is reported as trace_ms with trace_launches = 1   */
     float   level_trace_ms[16], level_shade_ms[16];   /* the same per level                              */
     int32_t trace_launches, shade_launches, resolve_launches;
-    int32_t reserved0;
+    int32_t pipeline;              /* which pipeline rendered the frame: 0 persistent frame kernel, 1 the same in
+                                      generations (RTX_RENDER_GENERATIONS or chosen by frame size), 2 level queues */
     /* primary_rays counts every pixel of this rank, as the reference casts one camera ray per pixel
      * (src/main.cpp:126-133).  The persistent frame kernel answers camera rays that cannot meet any primitive
      * (outside the screen window of the grid box / of every occupied fine cell) with the miss colour without
@@ -263,6 +266,14 @@ int  rtx_frame_status(rtx_ctx* ctx);
  * `stats` (nullable) forces a wait at the end of the call so the numbers are final. */
 int  rtx_render_device(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                        float* d_rgb_local, int32_t* d_prim_id_local, void* stream, rtx_stats* stats);
+
+/* Device times of the context's last frame, from the HIP events the library records on the frame's stream around it:
+ * frame_ms from before the fills to the completed framebuffer, kernel_ms the persistent frame kernel alone (the span
+ * of the trace / shade launches for the level-queue pipelines).  Waits for that frame.  For callers that keep frames
+ * in flight with rtx_render_device and want per-launch durations without a statistics call per frame (which would
+ * wait); either pointer may be NULL.  It has no counterpart in the reference (which prints one wall time per run,
+ * src/main.cpp:122-139). */
+int  rtx_frame_times(rtx_ctx* ctx, float* frame_ms, float* kernel_ms);
 
 /* Development aid: per-wave log of the last frame rendered with RTX_RENDER_COUNT_WORK by the persistent frame
  * kernel.  Eight values per wave: start, cursor exhausted, end (100 MHz clock), rounds, state updates, pixels drawn,

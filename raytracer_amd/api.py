@@ -29,12 +29,13 @@ RENDER_WAVES_4 = 128
 RENDER_HELPERS_EARLY = 256
 RENDER_HELPERS_LATE = 512
 RENDER_GENERATIONS = 1024
+RENDER_NO_GENERATIONS = 2048
 
 # Scheduling and tuning fields of rtx_render_params applied to every render call of this process unless the call
 # names them itself.  The library reads no environment variables; development tools (tools/) fill this from theirs,
 # and the test suite sets a round limit here so that a kernel that never ends cannot hang the machine.
 DEFAULTS = dict(tile_hint=True, tile_cull=True, helpers=True, frame_waves=0, walk_budget=0, ready_threshold=0,
-                drain_eighths=0, path_lanes=0, round_limit=0, generations=False, endgame_eighths=0)
+                drain_eighths=0, path_lanes=0, round_limit=0, generations=None, endgame_eighths=0)
 
 
 class RtxError(RuntimeError):
@@ -79,7 +80,7 @@ class RenderStats(C.Structure):
                 ("frame_ms", C.c_float), ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("resolve_ms", C.c_float),
                 ("level_trace_ms", C.c_float * 16), ("level_shade_ms", C.c_float * 16),
                 ("trace_launches", C.c_int32), ("shade_launches", C.c_int32), ("resolve_launches", C.c_int32),
-                ("reserved0", C.c_int32), ("traced_primary_rays", C.c_int64), ("culled_pixels", C.c_int64)]
+                ("pipeline", C.c_int32), ("traced_primary_rays", C.c_int64), ("culled_pixels", C.c_int64)]
 
     @property
     def total_rays(self):
@@ -151,6 +152,7 @@ def _load():
                                         C.POINTER(RenderStats)]),
         "rtx_render_device_noalloc": (C.c_int, [vp, C.POINTER(_Camera), C.POINTER(_RenderParams), vp, vp, vp]),
         "rtx_frame_status": (C.c_int, [vp]),
+        "rtx_frame_times": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rtx_download_wave_log": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
         "rtx_intersect": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rtx_camera_rays": (C.c_int, [vp, C.POINTER(_Camera), i32, i32, i32, vp, vp]),
@@ -170,7 +172,7 @@ EXPORTED_SYMBOLS = (
     "rtx_strerror", "rtx_last_error", "rtx_scene_load", "rtx_scene_parse", "rtx_scene_free", "rtx_scene_get_view",
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
-    "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_frame_times", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
     "rtx_save_image", "rtx_render_u8", "rtx_save_image_u8", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_device_count",
     "rtx_multi_set_scene", "rtx_multi_build_grid", "rtx_multi_get_grid_info", "rtx_multi_render", "rtx_multi_render_u8",
     "rtx_multi_render_device")
@@ -283,7 +285,7 @@ def _params(width, height, max_depth, eps_bias, search, tile_rows, rank, world, 
     flags |= ((0 if o["tile_hint"] else RENDER_NO_TILE_HINT) | (0 if o["tile_cull"] else RENDER_NO_TILE_CULL) |
               {0: RENDER_NO_HELPERS, 1: 0, True: 0, "late": RENDER_HELPERS_LATE, "early": RENDER_HELPERS_EARLY}[o["helpers"]] |
               {0: 0, 3: RENDER_WAVES_3, 4: RENDER_WAVES_4}[int(o["frame_waves"])] |
-              (RENDER_GENERATIONS if o["generations"] else 0))
+              {None: 0, True: RENDER_GENERATIONS, False: RENDER_NO_GENERATIONS}[o["generations"]])
     return _RenderParams(width, height, max_depth, eps_bias, search, tile_rows, rank, world, flags, workgroups_per_cu,
                          int(o["walk_budget"]), int(o["ready_threshold"]), int(o["drain_eighths"]), int(o["path_lanes"]), int(o["round_limit"]),
                          int(o["endgame_eighths"]), 0)
@@ -407,6 +409,12 @@ class Renderer:
     def frame_status(self):
         """Waits for this context's last asynchronous frame; raises RtxError (RTX_E_LIMIT) if it was abandoned."""
         _check(_load().rtx_frame_status(self._h))
+
+    def frame_times(self):
+        """(frame_ms, kernel_ms) of this context's last frame from the library's HIP events; waits for that frame."""
+        a, b = C.c_float(), C.c_float()
+        _check(_load().rtx_frame_times(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def wave_log(self):
         """[n_waves, 8] uint64 log of the last frame rendered with count_work (start, exhausted, end, rounds, updates,

@@ -31,6 +31,8 @@ using namespace rt;
 
 // traced-window pixels per resident lane from which the frame kernel runs with four waves per SIMD
 #define RTX_PIXELS_PER_LANE_FOR_4_WAVES 10.0
+// ... from which a frame launched with a share of the workgroups (frames in flight) runs the generation pipeline
+#define RTX_PIXELS_PER_LANE_FOR_GENERATIONS 12.0
 // ... below which a wave carries 32 paths and keeps its other lanes free for the shadow rays of fresh hits from the start
 // of the frame (48 paths below three times as many, when the launch has the GPU to itself)
 #define RTX_PIXELS_PER_LANE_FOR_EARLY_HELPERS 4.0
@@ -177,6 +179,7 @@ struct rtx_ctx {
     int* abort_host = nullptr;
     int* abort_dev = nullptr;
     bool frame_pending = false;   // a frame kernel was enqueued and its status has not been looked at yet
+    bool frame_timed = false;     // the events of the context bracket a frame (rtx_frame_times)
     size_t wave_log_waves = 0;    // waves logged by the last instrumented frame
 };
 
@@ -820,7 +823,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     const size_t pixels = (size_t)nl * p->width;
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
-    const bool generations = !level_queues && (p->flags & RTX_RENDER_GENERATIONS) != 0;
+    bool generations = !level_queues && (p->flags & RTX_RENDER_GENERATIONS) != 0;      // (or chosen below, by frame size)
     const int gen_terms = std::max(p->max_depth, 1);   // path terms a request of the generation pipeline carries
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
@@ -860,9 +863,6 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         // (instrumented frames log eight values per wave behind the 24 work counters)
         if ((rc = c->counters.reserve(CNT_TOTAL)) || (rc = c->work.reserve(24 + 8 * (size_t)blocks * (RTX_BLOCK / 64))) ||
             (rc = c->path_stack.reserve((size_t)blocks * RTX_BLOCK * global_levels)))
-            return rc;
-        if (generations &&
-            (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * 2 * RTX_GEN_CAP * (RTX_GEN_HEADER + gen_terms))))
             return rc;
         ws.counters = c->counters.p;
         ws.work = c->work.p;
@@ -908,6 +908,16 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     int frame_waves = pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_4_WAVES && blocks >= 2 * c->n_cus ? 4 : 3;
     if (p->flags & RTX_RENDER_WAVES_3) frame_waves = 3;
     if (p->flags & RTX_RENDER_WAVES_4) frame_waves = 4;
+    // Pipeline of the persistent launch.  Generations of one kind of ray make every state update dense but end each
+    // generation on its slowest ray and each path on a longer chain of generations: they win where a frame is bound by
+    // throughput and its end is hidden behind other frames -- a caller that keeps frames in flight (workgroups_per_cu
+    // given) with many pixels per lane (scene7 @ 4K, three frames in flight: 1.86 -> 1.64 ms per frame; half a frame per
+    // rank: 0.96 either way; a quarter or an eighth: slower) -- and lose on a lone frame (2.2 against 1.95 ms).
+    if (!level_queues && !no_alloc && !(p->flags & (RTX_RENDER_GENERATIONS | RTX_RENDER_NO_GENERATIONS)))
+        generations = p->workgroups_per_cu > 0 && pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_GENERATIONS;
+    if (generations &&
+        (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * 2 * RTX_GEN_CAP * (RTX_GEN_HEADER + gen_terms))))
+        return rc;
     bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
     if (p->flags & RTX_RENDER_NO_TILE_CULL) tile_cull = false;
     if (tile_cull) {
@@ -1054,6 +1064,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     HIP_TRY(hipEventRecord(ev[2], st));
     HIP_TRY(hipGetLastError());
     c->frame_pending = !level_queues;
+    c->frame_timed = true;
 
     if (stats) {
         if ((rc = take_frame_status(c, true))) return rc;
@@ -1082,9 +1093,11 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         (void)hipEventElapsedTime(&stats->frame_ms, ev[0], ev[2]);
         if (level_queues) {
             stats->trace_launches = stats->shade_launches = stats->resolve_launches = levels;
+            stats->pipeline = 2;
             (void)hipEventElapsedTime(&stats->resolve_ms, ev[1], ev[2]);
         } else {
             stats->trace_launches = 1;                 // the persistent frame kernel does everything
+            stats->pipeline = generations ? 1 : 0;
             (void)hipEventElapsedTime(&stats->trace_ms, ev[3], ev[1]);
         }
         if (count && !level_queues) c->wave_log_waves = (size_t)blocks * (RTX_BLOCK / 64);
@@ -1168,6 +1181,20 @@ int rtx_frame_status(rtx_ctx* c) {
     DeviceGuard guard(c->device);
     if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
     return take_frame_status(c, true);
+}
+
+int rtx_frame_times(rtx_ctx* c, float* frame_ms, float* kernel_ms) {
+    if (!c) { rtx_set_error("rtx_frame_times: null context"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    if (!c->have_events || !c->frame_timed) { rtx_set_error("rtx_frame_times: the context has rendered no frame"); return RTX_E_STATE; }
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    float a = 0.0f, b = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[3], c->ev[1]));
+    if (frame_ms) *frame_ms = a;
+    if (kernel_ms) *kernel_ms = b;
+    return RTX_OK;
 }
 
 int rtx_download_wave_log(rtx_ctx* c, uint64_t* out, int64_t max_waves, int64_t* n_waves) {

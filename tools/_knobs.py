@@ -7,7 +7,7 @@ every tool imports this module, which translates them once at start-up:
     RTX_TILE_FEEDBACK=0   no previous-frame scheduling hint        RTX_TILE_CULL=0        trace every tile
     RTX_HELPERS=0|2|3     no / early / late helpers                         RTX_FRAME_WAVES=3|4    force a register budget
     RTX_WALK_BUDGET=n     RTX_READY_THRESHOLD=n   RTX_DRAIN_NUM=n  RTX_ROUND_LIMIT=n
-    RTX_GENERATIONS=1     the generation pipeline
+    RTX_GENERATIONS=0|1   never / always the generation pipeline (unset: the library chooses)
 """
 import os
 
@@ -16,7 +16,7 @@ from raytracer_amd import api
 
 def apply(env=os.environ):
     d = api.DEFAULTS
-    for var, key in (("RTX_TILE_FEEDBACK", "tile_hint"), ("RTX_TILE_CULL", "tile_cull"), ("RTX_GENERATIONS", "generations")):
+    for var, key in (("RTX_TILE_FEEDBACK", "tile_hint"), ("RTX_TILE_CULL", "tile_cull"), ("RTX_GENERATIONS", "generations")):   # (unset: by frame size)
         if var in env:
             d[key] = int(env[var]) != 0
     if "RTX_HELPERS" in env:                                  # 0 none, 1 by frame size, 2 early, 3 late
