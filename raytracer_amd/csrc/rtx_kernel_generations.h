@@ -32,15 +32,6 @@
 #define RTX_GEN_CAP 128
 #define RTX_GEN_HEADER 3
 #define RTX_GEN_MAX_DEPTH 15
-#ifndef RT_GEN_TAIL_LANES
-#define RT_GEN_TAIL_LANES 0
-#endif
-#ifndef RT_GEN_TAIL_BUDGET
-#define RT_GEN_TAIL_BUDGET 8
-#endif
-#ifndef RT_GEN_AHEAD4
-#define RT_GEN_AHEAD4 0
-#endif
 #define RTX_GEN_REG_TERMS 6         // terms of a path that travel through registers when its record is rewritten
 
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
@@ -185,9 +176,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             while (__any(w.state != 2)) {
                 if (COUNT) log_rounds++;
-                int budget = f.walk_budget;
-                if (RT_GEN_TAIL_LANES > 0 && __popcll(__ballot(w.state != 2)) <= RT_GEN_TAIL_LANES) budget = RT_GEN_TAIL_BUDGET;
-                wave_round<MODE, SINGLE_XF, COUNT, PRIMS, (WAVES < 4 || RT_GEN_AHEAD4)>(sc, g, sp, occ, xf, l, w, r, kind == 2, budget, wc);
+                wave_round<MODE, SINGLE_XF, COUNT, PRIMS, (WAVES < 4)>(sc, g, sp, occ, xf, l, w, r, kind == 2, f.walk_budget, wc);
                 if (--rounds_left < 0) { abandoned = true; break; }
             }
             if (abandoned) break;

@@ -26,7 +26,8 @@ if os.path.exists(os.path.join(src, "configs.jsonl")):
 def summarize(cfg_dir, name):
     for f in glob.glob(os.path.join(cfg_dir, "trace", "*", "*kernel_stats.csv")):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"))
-    lines = [f"PMC summary ({tag}, {name}): k_frame, default pipeline, nested search, depth 5, every frame scheduled as a first frame; per "
+    kernel = "k_frame_gen (generation pipeline)" if name.endswith("_generations") else "k_frame (per-lane paths)"
+    lines = [f"PMC summary ({tag}, {name}): {kernel}, one frame at a time, nested search, depth 5, every frame scheduled as a first frame; per "
              "launch (mean over the launches of one run).",
              "Collected with rocprofv3 --pmc, one run per bracketed group (tools/profile_round.sh)."]
     vals = {}
@@ -34,7 +35,7 @@ def summarize(cfg_dir, name):
         for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
             per, dur = collections.defaultdict(list), {}
             for r in csv.DictReader(open(f)):
-                if "k_frame<" in r["Kernel_Name"]:
+                if "k_frame<" in r["Kernel_Name"] or "k_frame_gen<" in r["Kernel_Name"]:
                     per[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     dur[int(r["Start_Timestamp"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             agg = {k: sum(v) / max(len(v), 1) for k, v in per.items()}
@@ -55,7 +56,7 @@ def summarize(cfg_dir, name):
         fetch, write = v["FETCH_SIZE"] * 1024, v["WRITE_SIZE"] * 1024
         lines.append(f"    memory-side traffic per launch (L2 <-> fabric, Infinity Cache hits included): WRITE_SIZE {write / 1e6:.1f} MB, FETCH_SIZE "
                      f"{fetch / 1e6:.1f} MB as counted ({2 * fetch / 1e6:.1f} MB with the gfx950 x2 correction)")
-        if name == "scene7_4k":
+        if name == "scene7_4k_generations":
             json.dump({"traffic_bytes_per_launch": write + 2 * fetch, "write_bytes": write, "fetch_bytes_counted": fetch},
                       open(os.path.join(dst, f"{tag}_traffic.json"), "w"))
     open(os.path.join(dst, f"{tag}_{name}_pmc.txt"), "w").write("\n".join(lines) + "\n")
