@@ -782,6 +782,35 @@ def test_frames_in_flight_on_their_own_streams_and_contexts():
             r.close()
 
 
+def test_pipeline_choice_and_frame_times(renderer):
+    """The library runs a lone frame with per-lane paths and a large frame that shares the GPU (workgroups_per_cu given)
+    in generations; flags force either; rtx_stats.pipeline tells which ran; rtx_frame_times reports the device times of
+    an asynchronous frame.  All of them are the same frame."""
+    load(renderer, "scene7", 6)
+    W, H = 3840, 2160
+    d_rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+    want = None
+    for kw, pipeline in ((dict(), 0), (dict(workgroups_per_cu=2), 1), (dict(workgroups_per_cu=2, generations=False), 0),
+                         (dict(generations=True), 1), (dict(workgroups_per_cu=2, level_queues=True), 2)):
+        st = renderer.render_device(d_rgb.data_ptr(), 0, W, H, want_stats=True, **kw)
+        assert st.pipeline == pipeline, kw
+        got = d_rgb.cpu().numpy().view(np.int32)
+        want = got if want is None else want
+        assert np.array_equal(got, want), kw
+    # a small frame never runs in generations by itself
+    assert renderer.render_device(d_rgb.data_ptr(), 0, 320, 240, want_stats=True, workgroups_per_cu=2).pipeline == 0
+    renderer.render_device(d_rgb.data_ptr(), 0, W, H, workgroups_per_cu=2)           # asynchronous
+    frame_ms, kernel_ms = renderer.frame_times()
+    assert 0.5 < kernel_ms <= frame_ms < 50.0
+    fresh = rt.Renderer(0)
+    try:
+        with pytest.raises(rt.RtxError) as e:
+            fresh.frame_times()
+        assert e.value.code == -4
+    finally:
+        fresh.close()
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], [0] * 8, [0, 0, 0]])
 def test_several_gpus_behind_one_handle_reassemble_the_frame(renderer, devices):
     """rtx_multi_*: scene and grid on every rank, interleaved row tiles, rows copied into the frame of the first GPU by

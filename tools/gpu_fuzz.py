@@ -1,5 +1,5 @@
 """Development differential run on the GPU box: random scenes (the generator of tests/test_gpu_parity.py) rendered by
-the default pipeline in both builds of the frame kernel, with and without helpers, against the CPU oracle and against
+the persistent pipelines (per-lane paths with and without helpers, generations) in both builds of the frame kernel, against the CPU oracle and against
 the level-queue pipeline bit for bit.
 
     python tools/gpu_fuzz.py [first_seed] [n_seeds]
@@ -45,6 +45,12 @@ with tempfile.TemporaryDirectory() as tmp:
                             problems.append(f"{mode_name}: frame waves={waves} helpers={helpers} lanes={lanes} pass={k}")
                         if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
                             problems.append(f"{mode_name}: ray counts waves={waves} helpers={helpers}")
+                for endgame in (-1, 0, 40):             # the generation pipeline: no endgame, the default, the whole frame
+                    rgb, ids, st = r.render(0, 0, depth, mode, frame_waves=waves, generations=True, endgame_eighths=endgame)
+                    if not np.array_equal(ids, want_ids) or not np.array_equal(rgb.view(np.int32), want_rgb.view(np.int32)):
+                        problems.append(f"{mode_name}: generations waves={waves} endgame={endgame}")
+                    if (st.primary_rays, st.shadow_rays, st.reflection_rays) != (cnt["primary"], cnt["shadow"], cnt["reflect"]):
+                        problems.append(f"{mode_name}: ray counts generations waves={waves}")
         if problems:
             bad += 1
             print(f"seed {seed}: {problems}", flush=True)

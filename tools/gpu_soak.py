@@ -35,6 +35,8 @@ for name, sub, W, H, mode in cases:
             got.fill_(-1.0)
             # every third frame with helper lanes from the start and a varying number of paths per wave
             kw = dict(helpers="early", path_lanes=8 + (5 * k) % 56) if k % 3 == 2 else {}
+            if k % 4 == 1:                             # every fourth frame in generations, the endgame starting at varying points
+                kw = dict(generations=True, endgame_eighths=(-1, 0, 12, 40)[(k // 4) % 4])
             r.render_device(got.data_ptr(), got_ids.data_ptr(), W, H, 5, mode, frame_waves=waves, tile_hint=k % 2 == 0, **kw)
             torch.cuda.synchronize()
             if not (torch.equal(got.view(torch.int32), want.view(torch.int32)) and torch.equal(got_ids, want_ids)):
