@@ -29,20 +29,23 @@ import time
 
 
 def _frames_in_flight(world, sync_gather, hw_queues):
-    """Frames in flight of the throughput figure: enough to keep a GPU busy while the last paths of a frame drain --
-    three whole, half or quarter frames, six eighths of a frame (a rank's share shrinks with the number of ranks).  Six
-    streams need more than the four hardware queues a process gets by default: streams that share a queue run their
-    kernels one after the other (measured at 8 ranks: 0.37 ms per frame with 8 queues, 0.57 with 4 -- worse than three
-    frames of two workgroups per CU, 0.44), so with fewer than seven queues three frames it is."""
+    """(frames in flight, workgroups per CU of each frame's launch) of the throughput figure: enough frames to keep a GPU
+    busy while the last paths of a frame drain.  Measured on one GPU, ms per frame of a rank's share (tools/ab_inflight.sh,
+    tools/ab_ranks2.sh): whole frames 3 x 2 1.64, 4 x 2 1.65, 2 x 4 1.75; half frames 3 x 2 0.96, 4 x 2 0.92, 6 x 1 1.05;
+    quarters 3 x 2 0.67, 4 x 2 0.62, 6 x 1 0.60; eighths 3 x 2 0.41, 4 x 2 0.39, 6 x 1 0.35, 8 x 1 0.46.  Six streams need
+    more than the four hardware queues a process gets by default: streams that share a queue run their kernels one after
+    the other (eighths: 0.37 ms per frame with 8 queues, 0.57 with 4), so with fewer than seven queues four frames it is."""
     if sync_gather:
-        return 1
-    return 6 if world >= 8 and hw_queues >= 7 else 3
+        return 1, 0
+    if world >= 4 and hw_queues >= 7:
+        return 6, 1
+    return (4, 2) if world >= 2 else (3, 2)
 
 
 # GPU_MAX_HW_QUEUES must be set before the HIP runtime starts.  A value the operator has set is left alone (and the
 # number of frames in flight follows it); only a run that wants six frames in flight and finds the variable unset asks
 # for eight.  The effective value goes into the JSON line.
-if int(os.environ.get("WORLD_SIZE", "1")) >= 8 and "--sync-gather" not in sys.argv and "GPU_MAX_HW_QUEUES" not in os.environ:
+if int(os.environ.get("WORLD_SIZE", "1")) >= 4 and "--sync-gather" not in sys.argv and "GPU_MAX_HW_QUEUES" not in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 HW_QUEUES = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
 
@@ -158,15 +161,14 @@ def main():
     gi = r.build_grid(15, args.sub, grid_flags)
 
     as_u8 = args.gather == "u8"
-    # Three to six frames are in flight, each on its own stream and device context.  The end of a frame -- and, with many
+    # Three to six frames are in flight (see _frames_in_flight), each on its own stream and device context.  The end of a frame -- and, with many
     # ranks, all of a rank's small share of it -- is set by the longest chains of dependent rays rather than by the
     # amount of work; several frames side by side (each kernel launched with one or two workgroups per CU) fill the GPU,
     # and the gather of a frame travels while the next ones render.  Measured on one GPU: whole frames, scheduled as
     # first frames, 2.73 ms one at a time, 2.18 two in flight, 2.14 three; an eighth of a frame takes 1.4 ms however many
     # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (no gather: 0.33 ms per
     # frame against 0.51 with three frames, 0.75 with two).
-    depth = _frames_in_flight(world, args.sync_gather, HW_QUEUES)
-    wg_per_cu = 0 if depth == 1 else (2 if depth == 3 else 1)
+    depth, wg_per_cu = _frames_in_flight(world, args.sync_gather, HW_QUEUES)
     renderers = [r]
     for _ in range(1, depth):
         extra = rt.Renderer(local_rank)
