@@ -10,7 +10,9 @@ barrier + synchronize pairs, maximum over ranks.  Total work per step is fixed, 
 own HIP stream and device context), because the end of a frame is a handful of long chains of dependent rays that
 leave most of the GPU idle; `one_frame_at_a_time` holds the latency figure (one frame in flight, its gather completed
 before the next frame starts) at every N as well, so that a curve over N compares equals either way.
-Every timed frame is rendered as a first frame: the renderer's scheduling hint from the previous frame of the same
+Which pipeline of the persistent launch the frames run is the library's choice by frame size (`pipeline` in the JSON
+line: generations of one kind of ray for whole 4K frames that share the GPU, per-lane paths for a lone frame or a small
+share).  Every timed frame is rendered as a first frame: the renderer's scheduling hint from the previous frame of the same
 camera (an ordering of the screen tiles, never a result) is switched off, because the reference renders one frame
 per process.  The rates with the hint are reported beside it (`with_previous_frame_hint`).  `value` counts the
 reference's rays (one camera ray per pixel, one shadow ray per light and one mirror ray per hit); camera rays that

@@ -34,6 +34,8 @@ RENDER_NO_GENERATIONS = 2048
 # Scheduling and tuning fields of rtx_render_params applied to every render call of this process unless the call
 # names them itself.  The library reads no environment variables; development tools (tools/) fill this from theirs,
 # and the test suite sets a round limit here so that a kernel that never ends cannot hang the machine.
+# generations: None = the library picks the pipeline of the persistent launch by frame size, True / False force the
+# generation pipeline / per-lane paths; endgame_eighths: 0 = default, < 0 = never (see include/rtx.h).
 DEFAULTS = dict(tile_hint=True, tile_cull=True, helpers=True, frame_waves=0, walk_budget=0, ready_threshold=0,
                 drain_eighths=0, path_lanes=0, round_limit=0, generations=None, endgame_eighths=0)
 

@@ -915,6 +915,10 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     // rank: 0.96 either way; a quarter or an eighth: slower) -- and lose on a lone frame (2.2 against 1.95 ms).
     if (!level_queues && !no_alloc && !(p->flags & (RTX_RENDER_GENERATIONS | RTX_RENDER_NO_GENERATIONS)))
         generations = p->workgroups_per_cu > 0 && pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_GENERATIONS;
+    if (generations && c->n_materials >= (1 << 27)) {      // a request packs the material index beside the level
+        if (p->flags & RTX_RENDER_GENERATIONS) { rtx_set_error("render: the generation pipeline takes fewer than 2^27 materials"); return RTX_E_LIMIT; }
+        generations = false;
+    }
     if (generations &&
         (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * 2 * RTX_GEN_CAP * (RTX_GEN_HEADER + gen_terms))))
         return rc;

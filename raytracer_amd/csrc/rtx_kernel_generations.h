@@ -26,12 +26,12 @@
 //   S request: field 0 = (P, material << 4 | level)   1 = (N, tile slot)      2 = (incoming direction, pixel)
 //   M request: field 0 = (O, tile slot << 4 | level)  1 = (R, pixel)          2 unused
 //   fields 3 .. 3 + n_terms - 1: the terms (L xyz, material) of levels 0 .. level - 1
+// (level < 16, tile slot < 2^22 and material < 2^27 are the library's limits on max_depth, pixels and materials.)
 // Capacity: an S generation runs as soon as 64 requests wait, an N generation adds at most 64: fewer than 128
 // S requests at any time; an S generation adds at most 64 M requests and the next N generation takes them all.
 // ---------------------------------------------------------------------------------------------------
 #define RTX_GEN_CAP 128
 #define RTX_GEN_HEADER 3
-#define RTX_GEN_MAX_DEPTH 15
 #define RTX_GEN_REG_TERMS 6         // terms of a path that travel through registers when its record is rewritten
 
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
