@@ -181,7 +181,9 @@ typedef struct rtx_render_params {
     uint32_t flags;                /* RTX_RENDER_*                                                      */
     int32_t  workgroups_per_cu;    /* persistent frame kernel: workgroups launched per compute unit; <= 0 means 4.
                                       A caller that keeps several frames in flight on their own streams and
-                                      contexts gives each a share (e.g. 1) so that their kernels run side by side */
+                                      contexts gives each a share (e.g. 1) so that their kernels run side by side;
+                                      such a launch runs the generation pipeline when its frame is large enough
+                                      (see RTX_RENDER_GENERATIONS)                                              */
     /* tuning of the persistent frame kernel (results never depend on it); <= 0 selects the default */
     int32_t  walk_budget;          /* grid steps a lane may take per round (3)                              */
     int32_t  ready_threshold;      /* lanes with a finished ray that trigger a state update (56)            */
