@@ -34,7 +34,8 @@ def _frames_in_flight(world, sync_gather, hw_queues):
     """(frames in flight, workgroups per CU of each frame's launch) of the throughput figure: enough frames to keep a GPU
     busy while the last paths of a frame drain.  Measured on one GPU, ms per frame of a rank's share (tools/ab_inflight.sh,
     tools/ab_ranks2.sh): whole frames 3 x 2 1.64, 4 x 2 1.65, 2 x 4 1.75; half frames 3 x 2 0.96, 4 x 2 0.92, 6 x 1 1.05;
-    quarters 3 x 2 0.67, 4 x 2 0.62, 6 x 1 0.60; eighths 3 x 2 0.41, 4 x 2 0.39, 6 x 1 0.35, 8 x 1 0.46.  Six streams need
+    quarters 4 x 2 0.52, 6 x 1 0.51; eighths 4 x 2 0.32, 6 x 1 0.31 (8 x 1 0.46 before the library ran such launches
+    with its four-wave build).  Six streams need
     more than the four hardware queues a process gets by default: streams that share a queue run their kernels one after
     the other (eighths: 0.37 ms per frame with 8 queues, 0.57 with 4), so with fewer than seven queues four frames it is."""
     if sync_gather:

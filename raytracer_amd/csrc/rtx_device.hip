@@ -32,7 +32,7 @@ using namespace rt;
 // traced-window pixels per resident lane from which the frame kernel runs with four waves per SIMD
 #define RTX_PIXELS_PER_LANE_FOR_4_WAVES 10.0
 // ... from which a frame launched with a share of the workgroups (frames in flight) runs the generation pipeline
-#define RTX_PIXELS_PER_LANE_FOR_GENERATIONS 12.0
+#define RTX_PIXELS_PER_LANE_FOR_GENERATIONS 10.0
 // ... below which a wave carries 32 paths and keeps its other lanes free for the shadow rays of fresh hits from the start
 // of the frame (48 paths below three times as many, when the launch has the GPU to itself)
 #define RTX_PIXELS_PER_LANE_FOR_EARLY_HELPERS 4.0
@@ -902,17 +902,21 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     // Register budget of the frame kernel: with many pixels of the traced window per lane of the launch the frame is
     // bound by throughput and four waves per SIMD win (measured on scene7: 4K frame 2.16 against 2.35 ms); with few
     // it is a handful of chains of dependent rays per lane and the version with more registers per lane finishes
-    // each ray sooner (1440p and below, an eighth of a 4K frame).  A launch of one workgroup per CU (several frames
-    // in flight) gains no residency from the smaller budget.
+    // each ray sooner (1440p and below, an eighth of a 4K frame).  A launch that shares the GPU with other frames
+    // (workgroups_per_cu given) is a different matter: what counts then is how many workgroups of all those launches
+    // a CU holds at a time, four with the smaller budget against three (measured, six frames of one workgroup per CU
+    // in flight: a quarter of the 4K frame 0.59 -> 0.50 ms per frame, an eighth 0.35 -> 0.31).
     const double pixels_per_lane = (double)f.n_items0 / ((double)blocks * RTX_BLOCK);
     int frame_waves = pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_4_WAVES && blocks >= 2 * c->n_cus ? 4 : 3;
+    if (p->workgroups_per_cu > 0) frame_waves = 4;
     if (p->flags & RTX_RENDER_WAVES_3) frame_waves = 3;
     if (p->flags & RTX_RENDER_WAVES_4) frame_waves = 4;
     // Pipeline of the persistent launch.  Generations of one kind of ray make every state update dense but end each
     // generation on its slowest ray and each path on a longer chain of generations: they win where a frame is bound by
     // throughput and its end is hidden behind other frames -- a caller that keeps frames in flight (workgroups_per_cu
     // given) with many pixels per lane (scene7 @ 4K, three frames in flight: 1.86 -> 1.64 ms per frame; half a frame per
-    // rank: 0.96 either way; a quarter or an eighth: slower) -- and lose on a lone frame (2.2 against 1.95 ms).
+    // rank, four in flight: 0.96 -> 0.91; a quarter: 0.50 either way; an eighth: 0.31 -> 0.37) -- and lose on a lone
+    // frame (2.2 against 1.95 ms).
     if (!level_queues && !no_alloc && !(p->flags & (RTX_RENDER_GENERATIONS | RTX_RENDER_NO_GENERATIONS)))
         generations = p->workgroups_per_cu > 0 && pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_GENERATIONS;
     if (generations && c->n_materials >= (1 << 27)) {      // a request packs the material index beside the level
