@@ -82,6 +82,14 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
             if (nS + nM + nC == 0) break;               // nothing left on either stack, no pixels left to draw
         }
         S_n -= nS; M_n -= nM;
+        // (a generation pushes at most 64 requests onto either stack and the bounds above keep that much room.  The
+        // instrumented build, which the tests run, checks it: a change of the policy that broke the bounds gives the
+        // frame up there.  In the plain build the same check costs 3 % of the frame -- the extra exit from the loop
+        // moves the register allocation of the rounds.)
+        if (COUNT && (S_n > RTX_GEN_CAP - 64 || M_n > RTX_GEN_CAP - 64)) {
+            if (lane == 0) { f.counters[CNT_ABORT] = 1; *f.abort_host = 1; }
+            break;
+        }
         // What only the generation boundaries read of the frame, the scene and the grid comes from the kernel's
         // argument block by scalar loads here, not out of scalar registers held through the rounds.
         const __attribute__((address_space(4))) char* arg_block =
