@@ -306,12 +306,17 @@ def test_empty_scene_and_scene_without_lights(renderer):
     renderer.set_scene(sr)
     renderer.build_grid(15, 0)
     for mode in MODES:
-        rgb, ids, st = renderer.render(search=mode)
-        assert rgb.shape == (8, 16, 3) and not rgb.any() and (ids == -1).all()
-        assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (128, 0, 0)
+        for kw in PIPELINES.values():
+            rgb, ids, st = renderer.render(search=mode, **kw)
+            assert rgb.shape == (8, 16, 3) and not rgb.any() and (ids == -1).all()
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (128, 0, 0)
     load(renderer, "scene2")        # ambient only: no lights at all
-    rgb, ids, st = renderer.render(80, 60)
-    assert st.shadow_rays == 0 and st.reflection_rays > 0 and rgb.any()
+    want = None
+    for kw in PIPELINES.values():
+        rgb, ids, st = renderer.render(80, 60, **kw)
+        assert st.shadow_rays == 0 and st.reflection_rays > 0 and rgb.any()
+        want = rgb if want is None else want
+        assert np.array_equal(rgb.view(np.int32), want.view(np.int32))
 
 
 def test_coincident_triangles_keep_file_order(renderer):
@@ -330,12 +335,14 @@ def test_row_tiles_reassemble_to_the_single_gpu_frame(renderer, world, tile_rows
     load(renderer, "scene6")
     W, H = 200, 117
     full, full_ids, st_full = renderer.render(W, H, 5, rt.SEARCH_NESTED)
+    gen = world % 2 == 0                     # the even splits through the generation pipeline
     acc = np.full_like(full, np.nan)
     acc_ids = np.full_like(full_ids, -7)
     total = 0
     for rank in range(world):
         rows = rt.local_rows(H, tile_rows, rank, world)
-        rgb, ids, st = renderer.render(W, H, 5, rt.SEARCH_NESTED, tile_rows, rank, world)
+        rgb, ids, st = renderer.render(W, H, 5, rt.SEARCH_NESTED, tile_rows, rank, world, generations=gen)
+        assert st.pipeline == (1 if gen else 0)
         acc[rows] = rgb[rows]
         acc_ids[rows] = ids[rows]
         total += st.total_rays
