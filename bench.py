@@ -23,6 +23,7 @@ rate are reported at top level too (`rays_walked`, `Mrays_walked_per_s`).
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob as glob_mod
 import json
 import os
 import sys
@@ -48,7 +49,8 @@ def _frames_in_flight(world, sync_gather, hw_queues):
 # GPU_MAX_HW_QUEUES must be set before the HIP runtime starts.  A value the operator has set is left alone (and the
 # number of frames in flight follows it); only a run that wants six frames in flight and finds the variable unset asks
 # for eight.  The effective value goes into the JSON line.
-if int(os.environ.get("WORLD_SIZE", "1")) >= 4 and "--sync-gather" not in sys.argv and "GPU_MAX_HW_QUEUES" not in os.environ:
+_ONE_AT_A_TIME = any(a in sys.argv for a in ("--sync-gather", "--one-frame-at-a-time"))
+if int(os.environ.get("WORLD_SIZE", "1")) >= 4 and not _ONE_AT_A_TIME and "GPU_MAX_HW_QUEUES" not in os.environ:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 HW_QUEUES = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
 
@@ -144,6 +146,12 @@ def main():
         sys.exit(2)
     if args.share_gpu:
         local_rank = 0
+    visible = torch.cuda.device_count()
+    if not args.share_gpu and (args.gpus > visible or local_rank >= visible):
+        # before any timing: a run that cannot give every rank a GPU of its own must not produce a line
+        print(f"bench.py: --gpus {args.gpus} (local rank {local_rank}) but only {visible} GPU(s) are visible to this process; "
+              f"a rehearsal with ranks sharing a GPU needs --share-gpu --backend gloo", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     host_gather = args.backend == "gloo"
@@ -297,6 +305,12 @@ def main():
     if world > 1:
         dist.all_reduce(rays_local)
     rays = [int(v) for v in rays_local.tolist()]
+    # who took part: the device every rank rendered on, as the collective backend saw them
+    me = {"rank": rank, "device_index": local_rank, "device": torch.cuda.get_device_name(local_rank)}
+    participants = [me]
+    if world > 1:
+        participants = [None] * world
+        dist.all_gather_object(participants, me)
     total_rays = sum(rays[:3])
     walked_rays = rays[3] + rays[1] + rays[2]
 
@@ -335,16 +349,27 @@ def main():
             "hbm_algorithmic_GBs": frame_bytes / (kern[0] * 1e-3) / 1e9, "hbm_peak_GBs": PEAK_HBM_GBS,
             "traffic": None,
         }
+        # Counters of this kernel against the hardware's capacity, from the last committed rocprofv3 PMC passes of the same
+        # kernel on the same frame (bench.py does not run the profiler; the passes profile one launch at a time, the timed
+        # loop keeps several in flight: `valu_issue_busy_timed_loop` rescales the instruction count to the timed loop)
+        counters_file = sorted(glob_mod.glob(os.path.join(ROOT, "profiles", "*_counters.json")))
+        default_workload = (W, H, max_depth, args.sub) == (3840, 2160, 5, 6) and os.path.basename(args.scene) == "scene7.test"
+        if counters_file and world == 1 and args.search == "nested" and default_workload and gen:
+            with open(counters_file[-1]) as fh:
+                pmc = json.load(fh)
+            simd_cycles = 1024 * 2.4e9          # 256 CUs x 4 SIMDs, 2.4 GHz: a wave64 VALU instruction holds a SIMD for 4 cycles
+            roofline["counters"] = dict(pmc, source=os.path.relpath(counters_file[-1], ROOT),
+                                        measured_on="committed profile: one launch at a time (lone launch), not the timed loop",
+                                        valu_issue_busy_timed_loop=pmc["valu_insts_per_launch"] * 4 / (simd_cycles * ms_per_step * 1e-3))
         # memory-side bytes per launch from the last committed rocprofv3 PMC passes of this same kernel and frame
         # (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as gfx950 requires); bench.py itself does
         # not run the profiler
-        import glob
-        traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        default_workload = (W, H, max_depth, args.sub) == (3840, 2160, 5, 6) and os.path.basename(args.scene) == "scene7.test"
+        traffic_files = sorted(glob_mod.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
         if traffic_files and world == 1 and args.search == "nested" and default_workload:
             with open(traffic_files[-1]) as fh:
                 roofline["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
+            roofline["traffic_source"] = (os.path.relpath(traffic_files[-1], ROOT) + " (committed profile of one launch at a time: a lone "
+                                          "launch of this kernel on this frame, not the timed loop's overlapping launches)")
         out = {
             "metric": "Mrays/sec (primary+shadow+reflection) on scene7 @4K", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -365,6 +390,8 @@ def main():
                 "what": "the same loops with the screen tiles ordered by the path depths the previous frame of the same "
                         "camera recorded (order only; every ray of every frame is traced)"},
             "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "unset (HIP default: 4)"),
+            "backend": ("gloo on host copies (rehearsal)" if host_gather else "nccl (RCCL)") if world > 1 else "none (one rank: no collective runs)",
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "visible_devices": visible, "participants": participants,
             "data": "scenes/scene7.test (the reference's own scene file: 100000-triangle dragon), no randomness",
             "config": {"workload": f"scene7.test @ {W}x{H}, maxdepth {max_depth}, 15^3 grid, search={args.search}, "
                                    f"sub={gi.sub}, interleaved {args.tile_rows}-row tiles over {world} GPU(s), "

@@ -191,8 +191,10 @@ typedef struct rtx_render_params {
     int32_t  path_lanes;           /* paths a wave carries at a time; its other lanes stay free for the shadow rays of
                                       fresh hits from the start of the frame (default: 64, 48 or 32 by frame size) */
     int64_t  round_limit;          /* rounds a wave of the frame kernel may run before the frame is abandoned with
-                                      RTX_E_LIMIT; <= 0 derives the bound from the frame (every ray the frame can
-                                      hold times every step a ray can take: no valid frame reaches it)      */
+                                      RTX_E_LIMIT; <= 0 derives it from the frame: the smaller of what no valid frame
+                                      can exceed (every ray the frame can hold times every step a ray can take) and
+                                      max(2^24, 16 rounds per ray of a wave's even share of the pixels) -- a working
+                                      wave stays far below it, a kernel that would never end stops within seconds */
     int32_t  endgame_eighths;      /* generation pipeline: pixels left per lane of the launch, in eighths, from which a
                                       wave stops stocking up on paths and drains (both kinds of ray in one
                                       generation): shortens the end of a frame that has the GPU to itself; < 0 = never;
@@ -242,8 +244,10 @@ int  rtx_render(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
 int  rtx_render_u8(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params* p,
                    uint8_t* rgb8_out, int32_t order, int32_t* prim_id_out, rtx_stats* stats);
 
-/* rtx_render_device for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
- * that forbid hipMalloc).  It has no counterpart in the reference.  The call allocates nothing and frees nothing, on
+/* rtx_render_device for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+ * must not disturb another thread's stream capture with an allocation).  It has no counterpart in the reference.  The
+ * call itself has not been exercised under stream capture: it records, and for the context's previous frame queries,
+ * HIP events of the context.  The call allocates nothing and frees nothing, on
  * the host or on the device: the work cursors, the screen-tile map / classes / list / per-tile depths and the path
  * terms beyond the levels kept in LDS -- which rtx_render_device keeps in buffers the context allocates on first use --
  * live in a 10.2 MB array the library holds on every GPU it runs on for the life of the process.

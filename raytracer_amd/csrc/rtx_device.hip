@@ -14,10 +14,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "rtx.h"
@@ -297,17 +299,24 @@ void screen_window(const DevCamera& cam, f3 lo, f3 hi, int W, int H, bool have_p
     *y1 = (int)std::min((double)(H - 1), std::max(-1.0, std::ceil(ymax + margin)));
 }
 
-// Rounds no wave of the frame kernel can exceed on a valid frame.  Every round of a wave moves at least one of its
-// unfinished rays one step along its walk (or tests the candidates of the cell it stands on, after which the next
-// round moves it), so a wave's rounds are bounded by the steps of all rays it can ever hold: every ray of the frame,
-// in the worst case.  A ray crosses at most rx + ry + rz coarse cells and, inside each, 3 * sub fine cells; each
-// crossing is at most two rounds (look, leave).
-long long derived_round_limit(const rtx_ctx* c, const DevFrame& f, int max_depth) {
+// Rounds after which a wave of the frame kernel gives the frame up when the caller names no limit.  Two bounds, the
+// smaller one counts:
+//   * what no valid frame can exceed -- every round of a wave moves at least one of its unfinished rays one step along
+//     its walk (or tests the candidates of the cell it stands on, after which the next round moves it), a ray crosses at
+//     most rx + ry + rz coarse cells and, inside each, 3 * sub fine cells, each crossing at most two rounds (look, leave),
+//     and a wave can hold every ray of the frame in the worst case;
+//   * what a wave that works ends well below, so that a kernel that would never end is cut off in seconds and not in
+//     hours: 2^24 rounds, or sixteen rounds for every ray of an even share of the frame's pixels where that is more (a
+//     wave advances 64 rays per round and a ray takes six to ten rounds, so a wave that drew four times its share is
+//     still a factor of six below it; a 4K frame takes a few hundred rounds per wave).
+long long derived_round_limit(const rtx_ctx* c, const DevFrame& f, int max_depth, int blocks) {
     const double rays_per_path = (double)(max_depth + 1) * (double)(c->n_lights + 1);
     const DevGrid& g = c->dgrid;
     const double steps_per_ray = 2.0 * (double)(g.rx + g.ry + g.rz + 3) * (double)(3 * std::max(g.sub, 1) + 2) + 8.0;
     const double bound = ((double)f.n_items0 + 64.0) * rays_per_path * steps_per_ray;
-    return bound < 4.0e18 ? (long long)bound : (long long)4.0e18;
+    const double waves = (double)std::max(blocks, 1) * (RTX_BLOCK / 64);
+    const double guard = std::max(16777216.0, 16.0 * ((double)f.n_items0 / waves + 64.0) * rays_per_path);
+    return (long long)std::min(std::min(bound, guard), 4.0e18);
 }
 
 // Looks at the status word of the context's last frame; `wait` synchronises with the frame's end first.
@@ -974,7 +983,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         const int eighths = p->endgame_eighths != 0 ? std::max(p->endgame_eighths, 0) : (p->workgroups_per_cu > 0 ? 0 : RTX_GEN_ENDGAME_EIGHTHS);
         f.endgame_pixels = (int)std::min<long long>((long long)eighths * blocks * RTX_BLOCK / 8, 0x7fffffff);
     }
-    f.round_limit = p->round_limit > 0 ? (long long)p->round_limit : derived_round_limit(c, f, p->max_depth);
+    f.round_limit = p->round_limit > 0 ? (long long)p->round_limit : derived_round_limit(c, f, p->max_depth, blocks);
     f.abort_host = c->abort_dev;
     f.rgb = d_rgb;
     f.ids = d_ids;

@@ -31,8 +31,23 @@ struct FrameBudget {
     static constexpr int lds_levels = WAVES >= 4 ? 5 : 6;   // path levels whose terms live in LDS (deeper: global)
 };
 
-// layout of the first arguments of k_frame in its argument block
+// Layout of the first arguments of k_frame and k_frame_gen in the kernel's argument block.  Both kernels read what only
+// their state updates need through this struct (scalar loads from the argument block), so DevScene, DevGrid, DevSparse
+// and DevFrame must stay their four leading parameters, in this order.  By-value kernel arguments are laid out one
+// after the other, each at its own alignment -- the rule a struct's members follow -- which the assertions pin.
 struct FrameKernelArgs { DevScene sc; DevGrid g; DevSparse sp; DevFrame f; };
+constexpr size_t rtx_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static_assert(std::is_trivially_copyable<DevScene>::value && std::is_trivially_copyable<DevGrid>::value &&
+              std::is_trivially_copyable<DevSparse>::value && std::is_trivially_copyable<DevFrame>::value,
+              "kernel arguments are copied bytewise into the argument block");
+static_assert(offsetof(FrameKernelArgs, sc) == 0, "argument block: the scene comes first");
+static_assert(offsetof(FrameKernelArgs, g) == rtx_align_up(sizeof(DevScene), alignof(DevGrid)), "argument block: grid after scene");
+static_assert(offsetof(FrameKernelArgs, sp) == rtx_align_up(offsetof(FrameKernelArgs, g) + sizeof(DevGrid), alignof(DevSparse)),
+              "argument block: sparse grid after grid");
+static_assert(offsetof(FrameKernelArgs, f) == rtx_align_up(offsetof(FrameKernelArgs, sp) + sizeof(DevSparse), alignof(DevFrame)),
+              "argument block: frame after sparse grid");
+static_assert(alignof(DevScene) <= 8 && alignof(DevGrid) <= 8 && alignof(DevSparse) <= 8 && alignof(DevFrame) <= 8,
+              "argument block: the segment itself is only guaranteed 8-byte alignment for these");
 
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
 __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* path_stack, int global_levels) {

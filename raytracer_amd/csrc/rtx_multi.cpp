@@ -24,6 +24,15 @@
 
 namespace {
 
+// Keeps the caller's current device: every entry point that makes another device current puts the caller's back.
+struct DeviceKeeper {
+    int prev = -1;
+    DeviceKeeper() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceKeeper() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceKeeper(const DeviceKeeper&) = delete;
+    DeviceKeeper& operator=(const DeviceKeeper&) = delete;
+};
+
 struct Rank {
     int device = 0;
     rtx_ctx* ctx = nullptr;
@@ -31,6 +40,7 @@ struct Rank {
     float* rows = nullptr;            // this rank's rows of the frame (device memory on its GPU)
     int32_t* row_ids = nullptr;
     size_t rows_cap = 0, ids_cap = 0; // floats / ints allocated
+    bool direct = true;               // this GPU can address the first GPU's memory (itself, or peer access enabled)
     // worker
     std::thread thread;
     std::function<int()> job;
@@ -72,6 +82,10 @@ void worker(rtx_multi* m, Rank* r) {
             rc = job();
         } catch (const std::bad_alloc&) {
             rc = RTX_E_NOMEM;
+            rtx_set_error("out of host memory on a rank's worker thread");
+        } catch (...) {                                   // nothing may leave a worker thread: it would end the process
+            rc = RTX_E_STATE;
+            rtx_set_error("unexpected exception on a rank's worker thread");
         }
         if (rc != RTX_OK) err = rtx_last_error();
         {
@@ -116,6 +130,39 @@ hipError_t copy_to_root(void* dst, int root, const void* src, int device, size_t
     return hipMemcpyPeerAsync(dst, root, src, device, bytes, stream);
 }
 
+// All tiles of one rank in one copy.  The rank's rows are its tiles one after the other (`tile_bytes` each) and its
+// tiles stand `world` tiles apart in the frame: a pitched copy of `n_full` lines of tile_bytes, destination pitch
+// world * tile_bytes.  The frame's last tile may be short and is copied by itself.  A GPU that cannot address the
+// first GPU's memory (no peer access) copies tile by tile through the runtime's staging instead.
+hipError_t copy_tiles_to_root(char* frame, int root, const char* rows, const Rank& r, int rank, int world, int n_tiles, int tile_rows,
+                              int height, size_t row_bytes, hipStream_t stream) {
+    const size_t tile_bytes = (size_t)tile_rows * row_bytes;
+    int n_mine = 0, n_full = 0;
+    for (int t = rank; t < n_tiles; t += world) { n_mine++; if ((t + 1) * tile_rows <= height) n_full++; }
+    if (n_mine == 0) return hipSuccess;
+    if (!r.direct) {
+        size_t off = 0;
+        for (int t = rank; t < n_tiles; t += world) {
+            const size_t bytes = (size_t)std::min(tile_rows, height - t * tile_rows) * row_bytes;
+            const hipError_t e = copy_to_root(frame + (size_t)t * tile_bytes, root, rows + off, r.device, bytes, stream);
+            if (e != hipSuccess) return e;
+            off += bytes;
+        }
+        return hipSuccess;
+    }
+    if (n_full > 0) {
+        const hipError_t e = hipMemcpy2DAsync(frame + (size_t)rank * tile_bytes, (size_t)world * tile_bytes, rows, tile_bytes, tile_bytes,
+                                              (size_t)n_full, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (n_mine > n_full) {                                // the short last tile of the frame is this rank's
+        const int t = rank + n_full * world;
+        const size_t bytes = (size_t)(height - t * tile_rows) * row_bytes;
+        return hipMemcpyAsync(frame + (size_t)t * tile_bytes, rows + (size_t)n_full * tile_bytes, bytes, hipMemcpyDeviceToDevice, stream);
+    }
+    return hipSuccess;
+}
+
 // device buffer of the current device that only ever grows
 template <typename T>
 int grow(T** p, size_t* cap, size_t need) {
@@ -153,18 +200,12 @@ int render_into(rtx_multi* m, const rtx_camera* cam, const rtx_render_params* p,
             if ((rc = rtx_render_device(r.ctx, cam, &q, r.rows, d_ids ? r.row_ids : nullptr, r.stream, stats ? &r.stats : nullptr))) return rc;
             // local rows are this rank's tiles one after the other: tile j of the rank is image tile k + j * world
             const int n_tiles = (q.height + tile_rows - 1) / tile_rows;
-            size_t local_row = 0;
-            for (int t = k; t < n_tiles; t += world) {
-                const size_t rows_here = (size_t)std::min(tile_rows, q.height - t * tile_rows);
-                const size_t y0 = (size_t)t * tile_rows;
-                hipError_t e = copy_to_root(d_frame + y0 * W * 3, root, r.rows + local_row * W * 3, r.device, rows_here * W * 3 * sizeof(float), r.stream);
-                if (e != hipSuccess) return hip_fail("copy of a row tile to the first GPU", e);
-                if (d_ids) {
-                    e = copy_to_root(d_ids + y0 * W, root, r.row_ids + local_row * W, r.device, rows_here * W * sizeof(int32_t), r.stream);
-                    if (e != hipSuccess) return hip_fail("copy of a row tile to the first GPU", e);
-                }
-                local_row += rows_here;
-            }
+            hipError_t ce = copy_tiles_to_root((char*)d_frame, root, (const char*)r.rows, r, k, world, n_tiles, tile_rows, q.height,
+                                               W * 3 * sizeof(float), r.stream);
+            if (ce == hipSuccess && d_ids)
+                ce = copy_tiles_to_root((char*)d_ids, root, (const char*)r.row_ids, r, k, world, n_tiles, tile_rows, q.height,
+                                        W * sizeof(int32_t), r.stream);
+            if (ce != hipSuccess) return hip_fail("copy of a rank's row tiles to the first GPU", ce);
             const hipError_t e = hipStreamSynchronize(r.stream);
             if (e != hipSuccess) return hip_fail("hipStreamSynchronize", e);
             return rtx_frame_status(r.ctx);
@@ -195,6 +236,7 @@ extern "C" {
 int rtx_multi_create(rtx_multi** out, const int32_t* device_ids, int32_t n_devices) {
     if (!out || !device_ids || n_devices < 1 || n_devices > 64) { rtx_set_error("rtx_multi_create: bad argument (1..64 devices)"); return RTX_E_INVALID; }
     *out = nullptr;
+    DeviceKeeper keep;
     rtx_multi* m = new (std::nothrow) rtx_multi;
     if (!m) return RTX_E_NOMEM;
     m->ranks.resize((size_t)n_devices);
@@ -212,7 +254,11 @@ int rtx_multi_create(rtx_multi** out, const int32_t* device_ids, int32_t n_devic
         // direct copies into the first GPU's memory where the link allows; otherwise the runtime stages them
         if (r.device != device_ids[0]) {
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, r.device, device_ids[0]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+            r.direct = false;
+            if (hipDeviceCanAccessPeer(&can, r.device, device_ids[0]) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(device_ids[0], 0);
+                r.direct = pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled;
+            }
             (void)hipGetLastError();      // "already enabled" is not an error here
         }
     }
@@ -224,6 +270,7 @@ int rtx_multi_create(rtx_multi** out, const int32_t* device_ids, int32_t n_devic
 
 void rtx_multi_destroy(rtx_multi* m) {
     if (!m) return;
+    DeviceKeeper keep;
     {
         std::lock_guard<std::mutex> lock(m->mu);
         for (Rank& r : m->ranks) r.quit = true;
@@ -279,6 +326,7 @@ static int render_to_host(rtx_multi* m, const rtx_camera* cam, const rtx_render_
     if (p->width <= 0 || p->height <= 0) { rtx_set_error("rtx_multi_render: width/height must be positive"); return RTX_E_INVALID; }
     const size_t pixels = (size_t)p->width * (size_t)p->height;
     const int root = m->ranks[0].device;
+    DeviceKeeper keep;
     if (hipSetDevice(root) != hipSuccess) { rtx_set_error("hipSetDevice(%d) failed", root); return RTX_E_DEVICE; }
     int rc;
     if ((rc = grow(&m->d_frame, &m->frame_cap, pixels * 3))) return rc;

@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # No valid frame of this suite comes near 2^23 rounds per wave (a 4K frame takes a few hundred): a kernel that would
+    # never end is cut off after seconds and the test fails with RTX_E_LIMIT instead of hanging the GPU box.  Set before
+    # any test module builds a renderer of its own, not by the `renderer` fixture.
+    import raytracer_amd as rt
+    rt.api.DEFAULTS["round_limit"] = 1 << 23
 
 
 def scene_path(name):
@@ -23,9 +28,6 @@ def scene_path(name):
 def renderer():
     """One GPU context for the whole session (GPU tests only)."""
     import raytracer_amd as rt
-    # No valid frame of this suite comes near 2^23 rounds per wave (a 4K frame takes a few thousand): a kernel that
-    # would never end is cut off after seconds and the test fails with RTX_E_LIMIT instead of hanging the GPU box.
-    rt.api.DEFAULTS["round_limit"] = 1 << 23
     r = rt.Renderer(0)
     yield r
     r.close()

@@ -26,6 +26,48 @@ def test_library_exports_every_declared_symbol():
     assert sorted(api.EXPORTED_SYMBOLS) == names, "python binding and header disagree on the entry points"
 
 
+# struct of include/rtx.h -> its ctypes mirror in raytracer_amd/api.py
+MIRRORS = {"rtx_scene_view": api._SceneView, "rtx_camera": api._Camera, "rtx_grid_info": api.GridInfo,
+           "rtx_render_params": api._RenderParams, "rtx_stats": api.RenderStats}
+
+
+def test_ctypes_mirrors_match_the_header_as_a_c_compiler_lays_it_out(tmp_path):
+    """tests/c/abi_layout.c, compiled as C11 against include/rtx.h (which also proves the header is C), prints the size
+    of every struct and the offset and size of every field; the ctypes mirrors the tests reach the library through
+    must agree field by field, in the same order."""
+    import shutil
+    import subprocess
+    cc = shutil.which("cc") or shutil.which("gcc")
+    assert cc, "no C compiler"
+    exe = str(tmp_path / "abi_layout")
+    subprocess.run([cc, "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_layout.c"), "-o", exe], check=True)
+    lines = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    sizes, fields = {}, {}
+    for ln in lines:
+        t = ln.split()
+        if len(t) == 3 and t[0] == "struct":
+            sizes[t[1]] = int(t[2])
+        elif len(t) == 3:
+            st, f = t[0].split(".")
+            fields.setdefault(st, []).append((f, int(t[1]), int(t[2])))
+    assert sorted(sizes) == sorted(MIRRORS)
+    # every struct the header declares is printed, and every field of it
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rtx.h")).read(), flags=re.S)
+    declared = dict(re.findall(r"typedef struct (rtx_\w+) \{(.*?)\} \1;", text, flags=re.S))
+    assert sorted(declared) == sorted(MIRRORS)
+    for name, body in declared.items():
+        names = [re.sub(r"\[.*", "", d.strip().lstrip("*")) for decl in body.split(";") if decl.strip()
+                 for d in re.sub(r"^\s*(const\s+)?\w+\s*\*?", "", decl.strip(), count=1).split(",")]
+        assert names == [f for f, _, _ in fields[name]], f"{name}: abi_layout.c does not print every field"
+    for name, mirror in MIRRORS.items():
+        assert ctypes.sizeof(mirror) == sizes[name], name
+        assert [f for f, _ in mirror._fields_] == [f for f, _, _ in fields[name]], f"{name}: field order"
+        for f, off, size in fields[name]:
+            d = getattr(mirror, f)
+            assert (d.offset, d.size) == (off, size), f"{name}.{f}"
+
+
 def test_error_strings():
     lib = api._load()
     assert lib.rtx_strerror(0) == b"ok"

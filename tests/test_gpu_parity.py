@@ -86,7 +86,7 @@ def test_render_matches_golden(renderer, name, mode, pipeline):
 
 
 @pytest.mark.parametrize("name,w,h", [("scene1", 640, 480), ("scene4-specular", 640, 480), ("scene6", 640, 480),
-                                      ("scene5", 320, 240), ("scene2", 640, 480), ("scene3", 333, 211)])
+                                      ("scene5", 320, 240), ("scene2", 640, 480), ("scene3", 333, 211)])   # (scene5 and scene7 at 640x480: below)
 def test_full_size_configs_match_live_oracle(renderer, name, w, h):
     load(renderer, name)
     rgb_ref, ids_ref, _, cnt = RefScene(scene_path(name), counting=True).render(w, h, 5)
@@ -94,6 +94,51 @@ def test_full_size_configs_match_live_oracle(renderer, name, w, h):
         rgb, ids, st = renderer.render(w, h, 5, mode)
         assert_image_parity(rgb, ids, rgb_ref, ids_ref)
         assert st.total_rays == cnt["primary"] + cnt["shadow"] + cnt["reflect"]
+
+
+@pytest.mark.parametrize("name,sub", [("scene5", 0), ("scene7", 0), ("scene7", 6)])
+def test_scene5_and_scene7_at_their_files_own_size(renderer, name, sub):
+    """scene5 (res/scene5.test: 1000 spheres, 1000 transforms, two lights) and scene7 (res/scene7.test:3) at the 640x480
+    their files give, depth 5: every pixel against the committed oracle frame (tests/golden/make_golden_full.py), both
+    searches, both persistent pipelines; scene5 also against the oracle run here."""
+    import hashlib
+    g = np.load(os.path.join(GOLDEN, f"golden_{name}_full.npz"))
+    W, H = int(g["width"]), int(g["height"])
+    cnt = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    load(renderer, name, sub)
+    live = RefScene(scene_path(name)).render(W, H, 5) if name == "scene5" else None
+    for mode in MODES:
+        for kw in (dict(), dict(generations=True)):
+            rgb, ids, st = renderer.render(W, H, int(g["max_depth"]), mode, **kw)
+            assert np.array_equal(ids, g["ids"]), f"{int((ids != g['ids']).sum())} primary hit ids differ ({mode}, {kw})"
+            d = np.abs(rt.quantize(rgb).astype(np.int16) - g["rgb8"].astype(np.int16)).max(axis=2)
+            assert (d > 1).sum() == 0 and (d > 0).mean() <= 1e-3
+            same_bits = hashlib.sha256(rgb.tobytes()).hexdigest() == str(g["rgb_sha256"])
+            assert same_bits or np.abs(rgb.astype(np.float64).sum(axis=(1, 2)) - g["rgb_row_sums"]).max() <= FLOAT_TOL * 3 * W
+            assert (st.primary_rays, st.shadow_rays, st.reflection_rays) == (cnt["primary"], cnt["shadow"], cnt["reflect"])
+            if live is not None:
+                assert_image_parity(rgb, ids, live[0], live[1])
+
+
+def test_a_plain_c_program_renders_the_oracles_frame(tmp_path):
+    """tests/c/abi_render.c -- C11, nothing but include/rtx.h -- drives the library the way the reference's raytrace()
+    would (src/main.cpp:109-146): rtx_scene_load -> rtx_create -> rtx_set_scene -> rtx_build_grid -> rtx_render.  Its
+    raw float framebuffer and id map against the oracle, scene4-specular at the file's own 640x480, both searches."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "c", "bin", "abi_render")
+    assert os.path.exists(exe), "tests/c/bin/abi_render is missing: build it with __graft_entry__.build()"
+    W, H = 640, 480
+    rgb_ref, ids_ref, _, cnt = RefScene(scene_path("scene4-specular"), counting=True).render(W, H, 5)
+    for mode in MODES:
+        f_rgb, f_ids = str(tmp_path / f"out{mode}.rgb"), str(tmp_path / f"out{mode}.ids")
+        run = subprocess.run([exe, scene_path("scene4-specular"), str(W), str(H), "5", str(mode), f_rgb, f_ids],
+                             capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stderr
+        rgb = np.fromfile(f_rgb, np.float32).reshape(H, W, 3)
+        ids = np.fromfile(f_ids, np.int32).reshape(H, W)
+        assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+        assert run.stdout.split() == ["rays", str(cnt["primary"]), str(cnt["shadow"]), str(cnt["reflect"])]
 
 
 def test_scene7_4k_modes_agree_and_rows_match_oracle(renderer):
@@ -847,6 +892,35 @@ def test_several_gpus_behind_one_handle_reassemble_the_frame(renderer, devices):
         m.close()
     with pytest.raises(rt.RtxError):
         rt.MultiRenderer([0, 99])
+
+
+def test_several_gpus_behind_one_handle_leave_the_callers_device_alone(renderer):
+    """rtx_multi_* make their ranks' devices current on the calling thread for a moment; the caller's current device
+    must be what it was before, after create, set_scene, build_grid, render and destroy.  With one GPU in the machine
+    only device 0 exists and the check is trivial; with several the last one is made current and the handle lists the
+    others."""
+    n = torch.cuda.device_count()
+    mine = n - 1
+    torch.cuda.set_device(mine)
+    try:
+        sr = rt.SceneReader().readScene(scene_path("scene4-specular"))
+        devices = [d for d in range(n) if d != mine][:3] or [0, 0]
+        m = rt.MultiRenderer(devices)
+        assert torch.cuda.current_device() == mine
+        m.set_scene(sr)
+        m.build_grid(15, 0)
+        assert torch.cuda.current_device() == mine
+        m.render(160, 120, 5)
+        assert torch.cuda.current_device() == mine
+        m.close()
+        assert torch.cuda.current_device() == mine
+        # (torch caches its idea of the current device: ask the runtime as well)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        dev = ctypes.c_int(-1)
+        assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == mine
+    finally:
+        torch.cuda.set_device(0)
 
 
 def test_eight_bit_frame_is_converted_on_the_device(renderer):
