@@ -162,7 +162,7 @@ struct rtx_ctx {
     DevBuf<float4> hP, hN, hD, rO[2], rD[2], hL[RTX_MAX_LEVELS];
     DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
     DevBuf<float4> path_stack;
-    DevBuf<float4> gen_stacks;    // generation pipeline: the request stacks of every wave of the launch
+    DevBuf<float4> gen_stacks;    // generation pipeline: the request stacks and path slots of every wave of the launch
     DevBuf<unsigned char> tile_map;
     DevBuf<signed char> tile_class;
     DevBuf<int> tile_list, tile_cost[2];
@@ -833,7 +833,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     const bool serial = (p->flags & RTX_RENDER_SERIAL_LANES) != 0;
     const bool level_queues = serial || (p->flags & RTX_RENDER_LEVEL_QUEUES) != 0;
     bool generations = !level_queues && (p->flags & RTX_RENDER_GENERATIONS) != 0;      // (or chosen below, by frame size)
-    const int gen_terms = std::max(p->max_depth, 1);   // path terms a request of the generation pipeline carries
+    const int gen_levels = p->max_depth + 1;           // terms a path slot of the generation pipeline holds
     int blocks = c->n_cus * 4;   // 3 workgroups of 4 waves fit a CU at a time: the work cursors balance the rest
     if (p->workgroups_per_cu > 0) blocks = c->n_cus * std::min(p->workgroups_per_cu, 16);
     // path levels that do not fit the frame kernel's LDS strips (five levels in its four-wave build) live in global memory
@@ -933,7 +933,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         generations = false;
     }
     if (generations &&
-        (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * 2 * RTX_GEN_CAP * (RTX_GEN_HEADER + gen_terms))))
+        (rc = c->gen_stacks.reserve((size_t)blocks * (RTX_BLOCK / 64) * rtx_gen_wave_f4(gen_levels))))
         return rc;
     bool tile_cull = !level_queues && p->search == RTX_SEARCH_NESTED && f.n_items0 > 0 && tbx <= 0xffff && (nl + 7) / 8 <= 0x7fff;
     if (p->flags & RTX_RENDER_NO_TILE_CULL) tile_cull = false;
@@ -1056,7 +1056,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {
         float4* const strips = generations ? c->gen_stacks.p : ws.path_stack;
-        const int n_levels = generations ? gen_terms : global_levels;
+        const int n_levels = generations ? gen_levels : global_levels;
         if (p->search == RTX_SEARCH_REFERENCE_LISTS) launch_frame<RT_SEARCH_REF>(c, sc, f, strips, blocks, st, count, n_levels, frame_waves, generations);
         else launch_frame<RT_SEARCH_NESTED>(c, sc, f, strips, blocks, st, count, n_levels, frame_waves, generations);
         HIP_TRY(hipEventRecord(ev[1], st));

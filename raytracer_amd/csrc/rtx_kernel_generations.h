@@ -8,45 +8,64 @@
 // the handful of lanes that need it and costs the wave its full length.  Here a wave works in generations of
 // 64 rays of ONE kind:
 //   N generation  nearest-hit rays: mirror rays popped from the wave's M stack, the remaining lanes draw new
-//                 pixels (camera rays).  All 64 are traced to their end; then every hit becomes a shadow request
-//                 on the wave's S stack (position, normal, incoming direction, material, the path's terms so
-//                 far), every miss ends its path (src/main.cpp:104-106): the path's terms are folded, the pixel
-//                 is written.
-//   S generation  64 shadow requests popped from the S stack: one pass of shadow rays per light
-//                 (src/main.cpp:53-75), then the level's term (:97) and the mirror ray (:85-94) as a request on
-//                 the M stack, or the fold when the path is at its last level.
-// A path is not bound to a lane: between generations it lives in its request -- a record in device memory that
-// carries the terms of the levels above it -- so each section of a generation's prologue and epilogue runs on
-// (nearly) all 64 lanes.  The stacks are private to the wave (no cross-wave traffic, no atomics), last in first
-// out (deep paths first: the live records of a wave stay few and cached).  Every ray, hit, term and fold is the
-// arithmetic of k_frame, which is the reference's; only the schedule differs, so frames are bit-identical.
+//                 pixels (camera rays).  All 64 are traced to their end; then every hit pushes BOTH requests that
+//                 leave it -- the shadow request of its level (src/main.cpp:97) onto the S stack and, above the
+//                 last level, the mirror request (:85-94) onto the M stack: the two do not depend on each other
+//                 (trace() merely evaluates them one after the other), so the path's next nearest-hit ray is in
+//                 the very next N generation; every miss ends its path's chain (:104-106).
+//   S generation  64 shadow requests popped from the S stack: one pass of shadow rays per light (:53-75), then the
+//                 level's term (:97-102) goes into the path's slot.  An S generation pushes nothing.
+// A path is not bound to a lane.  While it lives it owns a slot of the wave's path pool: its per-level terms in
+// device memory, its pixel, and one word of LDS that counts what is still outstanding for it (shadow requests not
+// yet evaluated, plus one while its chain of nearest-hit rays goes on) and, once the chain has ended, holds the
+// deepest level that has a term.  Whichever lane brings that count to zero -- the lane that ends the chain or the
+// lane that evaluates the last outstanding shadow request -- folds the terms from the deepest level up
+// (src/main.cpp:99-102), writes the pixel and frees the slot.  Stacks and pool are private to the wave (no
+// cross-wave traffic), stacks are last in first out (deep paths first: the live records stay few and cached).
+// Every ray, hit, term and fold is the arithmetic of k_frame, which is the reference's; only the schedule differs,
+// so frames are bit-identical.
 //
-// Record layout (structure of arrays per stack: field k of slot s is q[k * RTX_GEN_CAP + s], so a generation's
-// pops and pushes are contiguous 1 KB reads and writes per field):
-//   S request: field 0 = (P, material << 4 | level)   1 = (N, tile slot)      2 = (incoming direction, pixel)
-//   M request: field 0 = (O, tile slot << 4 | level)  1 = (R, pixel)          2 unused
-//   fields 3 .. 3 + n_terms - 1: the terms (L xyz, material) of levels 0 .. level - 1
-// (level < 16, tile slot < 2^22 and material < 2^27 are the library's limits on max_depth, pixels and materials.)
-// Capacity: an S generation runs as soon as 64 requests wait, an N generation adds at most 64: fewer than 128
-// S requests at any time; an S generation adds at most 64 M requests and the next N generation takes them all.
+// Per wave in device memory (float4 units, see rtx_gen_wave_f4): S stack, 3 fields x RTX_GEN_CAP slots, structure of
+// arrays (field k of slot s at k * RTX_GEN_CAP + s, so a generation's pops and pushes are contiguous 1 KB accesses per
+// field); M stack, 2 fields; terms, n_levels per path slot.
+//   S request: field 0 = (P, material << 4 | level)   1 = (N, path slot)    2 = (incoming direction, -)
+//   M request: field 0 = (O, path slot << 4 | level)  1 = (R, -)
+//   term:      (L xyz of the level, material)
+// (level < 16, path slot < 2^9 and material < 2^27 are the library's limits.)
+// Capacities.  An S generation runs as soon as 64 shadow requests wait, a generation of mirror rays as soon as 64 mirror
+// requests do, and a generation of either kind of nearest-hit ray adds at most 64 to each stack: fewer than 128 on
+// either.  Live paths: at most the requests on both stacks plus the 64 rays of the generation in flight, fewer than
+// RTX_GEN_PATHS.
 // ---------------------------------------------------------------------------------------------------
 #define RTX_GEN_CAP 128
-#define RTX_GEN_HEADER 3
-#define RTX_GEN_REG_TERMS 6         // terms of a path that travel through registers when its record is rewritten
+#define RTX_GEN_S_FIELDS 3
+#define RTX_GEN_M_FIELDS 2
+#define RTX_GEN_PATHS 320
+// float4s of device memory per wave for frames of n_levels path levels
+__host__ __device__ constexpr size_t rtx_gen_wave_f4(int n_levels) {
+    return (size_t)RTX_GEN_CAP * (RTX_GEN_S_FIELDS + RTX_GEN_M_FIELDS) + (size_t)RTX_GEN_PATHS * (size_t)n_levels;
+}
 
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
-__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_terms) {
+__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_levels) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+    // per path slot: low half = what is outstanding for the path, high half = 1 + its deepest level with a term (once
+    // its chain has ended, 0 before)
+    __shared__ int path_state[RTX_BLOCK / 64][RTX_GEN_PATHS];
+    __shared__ int2 path_pixel[RTX_BLOCK / 64][RTX_GEN_PATHS];        // local pixel index, 8x8 block of the cost map
+    __shared__ unsigned short free_slot[RTX_BLOCK / 64][RTX_GEN_PATHS];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = {};
     const int wave = (int)(threadIdx.x >> 6), lane = wave_lane();
     WaveLds& l = lds[wave];
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
-    const size_t stack_f4 = (size_t)RTX_GEN_CAP * (RTX_GEN_HEADER + n_terms);
-    float4* const qS = queues + (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * 2 * stack_f4;
-    float4* const qM = qS + stack_f4;
+    for (int i = lane; i < RTX_GEN_PATHS; i += 64) free_slot[wave][i] = (unsigned short)i;
+    int n_free = RTX_GEN_PATHS;                         // free path slots (wave-uniform): free_slot[0 .. n_free)
+    float4* const qS = queues + (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * rtx_gen_wave_f4(n_levels);
+    float4* const qM = qS + RTX_GEN_CAP * RTX_GEN_S_FIELDS;
+    float4* const terms = qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS;
     WorkCounters wc = {};
 
     Walker<MODE> w;
@@ -65,28 +84,34 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
     int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0;
     if (COUNT) log_start = wall_clock64();
     const unsigned long long below = (1ull << lane) - 1ull;
-    const bool mixing = n_terms <= RTX_GEN_REG_TERMS;   // (deeper terms are copied record to record, pure generations only)
 
     for (;;) {
         // ---- which generation ----------------------------------------------------------------------------------
         int nS = 0, nM = 0, nC = 0;
         if (S_n >= 64) nS = 64;
-        else {
-            nM = min(M_n, 64);
-            nC = exhausted ? 0 : min(64 - nM, new_paths);
+        else if (!exhausted && !endgame) {
+            // A generation of one kind while the frame lasts: 64 mirror rays once that many wait, else 64 new pixels.  (Camera
+            // rays and mirror rays in one generation cost both kinds' set-up every time, and the camera rays of a tile, which
+            // walk the same cells and end together, would wait for the mirror rays' longer walks.)
+            if (M_n >= 64) nM = 64;
+            else nC = new_paths;
+        } else {
             // Toward the end of the frame the wave drains: what is left of both stacks goes into the same generation (no
-            // path waits for a generation of the other kind) and new pixels only fill the lanes that are left, so that
-            // the last pixels go to the waves that have run out of work, not onto the stacks of those that have not.
-            if ((exhausted || endgame) && mixing) { nS = min(S_n, 64 - nM); nC = min(nC, 64 - nM - nS); }
-            else if (exhausted && S_n > 0 && S_n >= M_n) { nS = min(S_n, 64); nM = 0; }
+            // request waits for a generation of its kind to fill) and new pixels only take the lanes that are left, so that
+            // the last pixels go to the waves that have run out of work, not onto the stacks of those that have not.  A
+            // path then advances one level per generation: its mirror ray and the shadow rays of the level before it
+            // travel together.
+            nM = min(M_n, 64);
+            nS = min(S_n, 64 - nM);
+            nC = exhausted ? 0 : min(new_paths, 64 - nM - nS);
             if (nS + nM + nC == 0) break;               // nothing left on either stack, no pixels left to draw
         }
         S_n -= nS; M_n -= nM;
-        // (a generation pushes at most 64 requests onto either stack and the bounds above keep that much room.  The
-        // instrumented build, which the tests run, checks it: a change of the policy that broke the bounds gives the
-        // frame up there.  In the plain build the same check costs 3 % of the frame -- the extra exit from the loop
-        // moves the register allocation of the rounds.)
-        if (COUNT && (S_n > RTX_GEN_CAP - 64 || M_n > RTX_GEN_CAP - 64)) {
+        // (a generation of nearest-hit rays pushes at most 64 requests onto either stack and starts at most nC paths, and the
+        // bounds above keep that much room.  The instrumented build, which the tests run, checks it: a change of the policy that broke the
+        // bounds gives the frame up there.  In the plain build the same check costs 3 % of the frame -- the extra exit from
+        // the loop moves the register allocation of the rounds.)
+        if (COUNT && nM + nC > 0 && (S_n > RTX_GEN_CAP - 64 || M_n > RTX_GEN_CAP - 64 || n_free < nC)) {
             if (lane == 0) { f.counters[CNT_ABORT] = 1; *f.abort_host = 1; }
             break;
         }
@@ -106,18 +131,20 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
         // ---- prologue ------------------------------------------------------------------------------------------
         // kind 0: no request this generation; 1: nearest-hit ray (mirror or camera); 2: shadow request
         int kind = 0, src = -1, level = 0, pix = -1, tslot = 0;
+        int slot = -1;                                    // the path's slot (nearest-hit rays above level 0, shadow requests)
         f3 rayDir = mk(0, 0, 1), O = mk(0, 0, 0), D = mk(0, 0, 1);
         float tl = FLT_MAX;
         if (lane < nS) {
             kind = 2; src = S_n + lane;
             const float4 h2 = qS[2 * RTX_GEN_CAP + src];
-            rayDir = mk(h2.x, h2.y, h2.z); pix = as_int(h2.w);
+            rayDir = mk(h2.x, h2.y, h2.z);
         } else if (lane < nS + nM) {
-            kind = 1; src = M_n + lane - nS;
-            const float4 h0 = qM[src], h1 = qM[RTX_GEN_CAP + src];
+            kind = 1;
+            const int from = M_n + lane - nS;
+            const float4 h0 = qM[from], h1 = qM[RTX_GEN_CAP + from];
             O = mk(h0.x, h0.y, h0.z);
-            level = as_int(h0.w) & 15; tslot = (int)((unsigned)as_int(h0.w) >> 4);
-            rayDir = mk(h1.x, h1.y, h1.z); pix = as_int(h1.w);
+            level = as_int(h0.w) & 15; slot = (int)((unsigned)as_int(h0.w) >> 4);
+            rayDir = mk(h1.x, h1.y, h1.z);
             D = normalize3(rayDir);                       // src/main.cpp:82
         }
         if (nC > 0) {
@@ -148,7 +175,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
                         O = fu.cam.eye;
                         rayDir = camera_ray(fu.cam, x, y);
                         D = normalize3(rayDir);           // src/main.cpp:82
-                        kind = 1; src = -1; level = 0;
+                        kind = 1; level = 0;
                     }
                 }
             }
@@ -184,8 +211,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
             if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
             // (The round limit is a second way out of this loop on purpose.  Folding it into the loop's condition, or counting
             // the rounds of a generation and checking afterwards, looks tidier and makes the frame 14 - 20 % slower: the
-            // register allocator then spills inside the walk and test loops -- 138 scratch accesses in the kernel against
-            // 29, all of which now sit in the generation boundaries.)
+            // register allocator then spills inside the walk and test loops.)
             while (__any(w.state != 2)) {
                 if (COUNT) log_rounds++;
                 wave_round<MODE, SINGLE_XF, COUNT, PRIMS, (WAVES < 4)>(sc, g, sp, occ, xf, l, w, r, kind == 2, f.walk_budget, wc);
@@ -217,28 +243,24 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
         }
 
         // ---- epilogue ------------------------------------------------------------------------------------------
-        // a path that ends folds its terms from the deepest level up (src/main.cpp:99-102) and writes its pixel
-        const float4* const q_src = kind == 2 ? qS : qM;
-        const auto end_path = [&](f3 C, int top_below) {      // C: the fold so far; terms top_below .. 0 come from the record
-            for (int d = top_below; d >= 0; d--) {
-                const float4 s4 = q_src[(RTX_GEN_HEADER + d) * RTX_GEN_CAP + src];
-                const float* m = su.mats + 16 * as_int(s4.w);
-                C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
-            }
-            fu.rgb[3 * pix] = C.x;
-            fu.rgb[3 * pix + 1] = C.y;
-            fu.rgb[3 * pix + 2] = C.z;
-        };
+        // What each lane's ray means for its path: `delta` is what it adds to the path's state word -- +1 for the shadow
+        // request of a hit, -1 for an evaluated shadow request, and for the lane that ends the chain -1 together with the
+        // deepest level that has a term (+1, in the high half).
         bool push_s = false, push_m = false;
+        int delta = 0;
         f3 P = mk(0, 0, 0), N = mk(0, 0, 1);
         int material = 0;
-        float4 rec = make_float4(0, 0, 0, 0);
         if (kind == 1) {
             if (!w.hit) {                                   // src/main.cpp:104-106
-                if (level == 0 && fu.ids) fu.ids[pix] = -1;
-                end_path(mk(0, 0, 0), level - 1);
-                if (fu.tile_cost && fu.tile_cost[tslot] < level + 1) atomicMax(fu.tile_cost + tslot, level + 1);
-                if (COUNT) log_deepest = max(log_deepest, level);
+                if (level == 0) {                           // a camera ray that meets nothing: the pixel is the miss colour
+                    if (fu.ids) fu.ids[pix] = -1;
+                    fu.rgb[3 * pix] = 0.0f;
+                    fu.rgb[3 * pix + 1] = 0.0f;
+                    fu.rgb[3 * pix + 2] = 0.0f;
+                    if (fu.tile_cost && fu.tile_cost[tslot] < 1) atomicMax(fu.tile_cost + tslot, 1);
+                } else {
+                    delta = (level << 16) - 1;              // terms of levels 0 .. level - 1
+                }
             } else {
                 if (COUNT) wc.nearest_hits++;
                 const int prim = r.best_prim;
@@ -246,61 +268,73 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
                 atomicAdd(&hit_count[wave][level], 1);
                 if (level == 0 && fu.ids) fu.ids[pix] = prim;
                 push_s = true;
+                push_m = level < fu.max_depth;
+                delta = push_m ? 1 : ((level + 1) << 16);   // (+1 for the request, and at the last level -1 with the top level)
             }
         } else if (kind == 2) {
             const float4 h0 = qS[src], h1 = qS[RTX_GEN_CAP + src];
-            P = mk(h0.x, h0.y, h0.z); N = mk(h1.x, h1.y, h1.z);
             material = (int)((unsigned)as_int(h0.w) >> 4); level = as_int(h0.w) & 15;
-            tslot = as_int(h1.w);
+            slot = as_int(h1.w);
             // the level's term (src/main.cpp:97-102)
             const float* m = su.mats + 16 * material;
             const f3 Lsum = mk(m[0], m[1], m[2]) + mk(m[9], m[10], m[11]) + clamp_rgb(acc);
-            rec = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
-            if (level < fu.max_depth) {
-                push_m = true;
-            } else {
-                end_path(clamp_rgb(Lsum + mk(m[6], m[7], m[8]) * mk(0, 0, 0)), level - 1);
-                if (fu.tile_cost && fu.tile_cost[tslot] < level + 2) atomicMax(fu.tile_cost + tslot, level + 2);
-                if (COUNT) log_deepest = max(log_deepest, level + 1);
-            }
+            terms[slot * n_levels + level] = make_float4(Lsum.x, Lsum.y, Lsum.z, as_float(material));
+            delta = -1;
         }
-        // Pushes: the k-th pushing lane takes the k-th free slot of the other kind's stack.  In a mixed generation those
-        // slots may be the very records lanes of the other kind are still reading, so every lane first reads what it
-        // carries over (the terms of the levels above, through registers), then all lanes write.
-        const unsigned long long mask_s = __ballot(push_s), mask_m = __ballot(push_m);
-        float4 carried[RTX_GEN_REG_TERMS];
-#pragma unroll
-        for (int d = 0; d < RTX_GEN_REG_TERMS; d++) {
-            carried[d] = make_float4(0, 0, 0, 0);
-            if ((push_s || push_m) && d < level) carried[d] = q_src[(RTX_GEN_HEADER + d) * RTX_GEN_CAP + src];
-        }
+        // every lane has read what it needs of the stacks' records (a generation of both kinds pushes over the very
+        // records its shadow lanes popped), and the terms stored above have landed before a fold reads them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        float4* const q_dst = push_s ? qS : qM;
-        int at = 0;
+        // paths that begin: a camera ray that hit takes a free slot; its state starts with the chain and one request
+        const bool begins = push_s && level == 0;
+        const unsigned long long mask_b = __ballot(begins);
+        if (begins) {
+            slot = (int)free_slot[wave][n_free - 1 - __popcll(mask_b & below)];
+            path_state[wave][slot] = 1;
+            path_pixel[wave][slot] = make_int2(pix, tslot);
+        }
+        n_free -= __popcll(mask_b);
+        wave_lds_sync();
+        int state = 1;
+        if (delta != 0) state = atomicAdd(&path_state[wave][slot], delta) + delta;
+        const bool folds = delta != 0 && (state & 0xffff) == 0;
+        // Pushes: the k-th pushing lane takes the k-th free slot of its stack.
+        const unsigned long long mask_s = __ballot(push_s), mask_m = __ballot(push_m);
         if (push_s) {
-            at = S_n + __popcll(mask_s & below);
+            const int at = S_n + __popcll(mask_s & below);
             qS[at] = make_float4(P.x, P.y, P.z, as_float((material << 4) | level));
-            qS[RTX_GEN_CAP + at] = make_float4(N.x, N.y, N.z, as_float(tslot));
-            qS[2 * RTX_GEN_CAP + at] = make_float4(rayDir.x, rayDir.y, rayDir.z, as_float(pix));
+            qS[RTX_GEN_CAP + at] = make_float4(N.x, N.y, N.z, as_float(slot));
+            qS[2 * RTX_GEN_CAP + at] = make_float4(rayDir.x, rayDir.y, rayDir.z, 0.0f);
         }
         if (push_m) {                                        // src/main.cpp:85-94
             const f3 V = normalize3(-rayDir);
             const f3 R = (2.0f * dot3(V, N) * N) - V;
             const f3 On = P + fu.bias * R;
-            at = M_n + __popcll(mask_m & below);
-            qM[at] = make_float4(On.x, On.y, On.z, as_float((tslot << 4) | (level + 1)));
-            qM[RTX_GEN_CAP + at] = make_float4(R.x, R.y, R.z, as_float(pix));
-            qM[(RTX_GEN_HEADER + level) * RTX_GEN_CAP + at] = rec;
-        }
-        if (push_s || push_m) {
-#pragma unroll
-            for (int d = 0; d < RTX_GEN_REG_TERMS; d++)
-                if (d < level) q_dst[(RTX_GEN_HEADER + d) * RTX_GEN_CAP + at] = carried[d];
-            for (int d = RTX_GEN_REG_TERMS; d < level; d++)
-                q_dst[(RTX_GEN_HEADER + d) * RTX_GEN_CAP + at] = q_src[(RTX_GEN_HEADER + d) * RTX_GEN_CAP + src];
+            const int at = M_n + __popcll(mask_m & below);
+            qM[at] = make_float4(On.x, On.y, On.z, as_float((slot << 4) | (level + 1)));
+            qM[RTX_GEN_CAP + at] = make_float4(R.x, R.y, R.z, 0.0f);
         }
         S_n += __popcll(mask_s);
         M_n += __popcll(mask_m);
+        // a path with nothing outstanding folds its terms from the deepest level up (src/main.cpp:99-102), writes its
+        // pixel and gives its slot back
+        const unsigned long long mask_f = __ballot(folds);
+        if (folds) {
+            const int top = (state >> 16) - 1;
+            const int2 where = path_pixel[wave][slot];
+            f3 C = mk(0, 0, 0);
+            for (int d = top; d >= 0; d--) {
+                const float4 s4 = terms[slot * n_levels + d];
+                const float* m = su.mats + 16 * as_int(s4.w);
+                C = clamp_rgb(mk(s4.x, s4.y, s4.z) + mk(m[6], m[7], m[8]) * C);
+            }
+            fu.rgb[3 * where.x] = C.x;
+            fu.rgb[3 * where.x + 1] = C.y;
+            fu.rgb[3 * where.x + 2] = C.z;
+            if (fu.tile_cost && fu.tile_cost[where.y] < top + 2) atomicMax(fu.tile_cost + where.y, top + 2);
+            if (COUNT) log_deepest = max(log_deepest, top + 1);
+            free_slot[wave][n_free + __popcll(mask_f & below)] = (unsigned short)slot;
+        }
+        n_free += __popcll(mask_f);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (COUNT) wc.c_update += __builtin_readcyclecounter() - c0;
     }

@@ -53,17 +53,31 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (no LDS round trips): four shifted
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive operands (no LDS round trips): four shifted
 // adds inside each row of 16 lanes, then the totals of rows 0 and 2 are broadcast into rows 1 and 3 (row_bcast:15,
-// row mask 0b1010) and the total of rows 0-1 into rows 2-3 (row_bcast:31, row mask 0b1100).  Lanes without a
-// source lane add the `old` operand, 0.  Every lane must be active.
+// row mask 0b1010) and the total of rows 0-1 into rows 2-3 (row_bcast:31, row mask 0b1100).  A lane without a source
+// lane, or outside the row mask, keeps its value.  Every lane must be active.
+// Written as assembly: from the intrinsic form the compiler makes a zero, a moved copy and an add of every step (18
+// vector instructions), here a step is the one add that reads its first operand through the shift.  A vector
+// register written by a vector instruction may be read through a shift two wait states later at the earliest;
+// the compiler does not look into the block, so the block itself keeps that distance, also to whatever stands
+// before and behind it.
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 
@@ -349,14 +363,24 @@ __device__ __forceinline__ f3 xf_dir(const XfRegs& x, f3 v) {
               (x.m[2] * v.x + x.m[5] * v.y) + (x.m[8] * v.z + x.m[11] * 0.0f));
 }
 
-// Inclusive running maximum over the 64 lanes (same data-parallel-primitive pattern as the prefix sum; values >= 0)
+// Inclusive running maximum over the 64 lanes (the prefix sum's pattern, same form; any values: a lane without a
+// source lane keeps its own)
 __device__ __forceinline__ int wave_inclusive_max(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return v;
 }
 

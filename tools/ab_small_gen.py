@@ -22,7 +22,7 @@ for name in ("scene1", "scene4-specular", "scene5", "scene6"):
 
     line = [f"{name}: default {ms(generations=False):.3f}"]
     for waves in (3, 4):
-        for e in (-1, 8, 32):
+        for e in (-1, 8, 64, 1000000):
             line.append(f"gen w{waves} e{e} {ms(generations=True, frame_waves=waves, endgame_eighths=e):.3f}")
     print("  ".join(line), flush=True)
 r.close()
