@@ -436,6 +436,10 @@ def main():
                 torch.cuda.synchronize()
                 whole = whole_q
             out["image_check"] = bool(torch.equal(img.to(dev), whole))
+            if not out["image_check"]:
+                bad = (img.to(dev) != whole).any(dim=2).nonzero()
+                out["image_check_detail"] = {"pixels_differing": int(bad.shape[0]), "first": bad[:4].tolist(),
+                                             "rows": sorted(set(bad[:, 0].tolist()))[:24]}
     if rank == 0:
         print(json.dumps(out))
     for rr in renderers:

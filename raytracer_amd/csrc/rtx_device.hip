@@ -74,14 +74,15 @@ using namespace rt;
 #define RTX_NOALLOC_MAX_DEPTH 6
 #define RTX_NA_ALIGN(x) (((size_t)(x) + 255) & ~(size_t)255)
 #define RTX_NA_COUNTERS 0
-#define RTX_NA_TILE_MAP (RTX_NA_COUNTERS + RTX_NA_ALIGN(CNT_TOTAL * sizeof(int)))
-#define RTX_NA_TILE_CLASS (RTX_NA_TILE_MAP + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES + 16))
+#define RTX_NA_SYNC (RTX_NA_COUNTERS + RTX_NA_ALIGN(CNT_TOTAL * sizeof(int)))
+#define RTX_NA_TILE_MAP (RTX_NA_SYNC + RTX_NA_ALIGN(8 * sizeof(unsigned)))
+#define RTX_NA_TILE_CLASS (RTX_NA_TILE_MAP + RTX_NA_ALIGN((RTX_NOALLOC_MAX_TILES + 4) * sizeof(unsigned)))
 #define RTX_NA_TILE_LIST (RTX_NA_TILE_CLASS + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES))
 #define RTX_NA_TILE_COST0 (RTX_NA_TILE_LIST + RTX_NA_ALIGN(RTX_NOALLOC_MAX_TILES * sizeof(int)))
 #define RTX_NA_TILE_COST1 (RTX_NA_TILE_COST0 + RTX_NA_ALIGN((RTX_NOALLOC_MAX_TILES + 4) * sizeof(int)))
 #define RTX_NA_PATH_STACK (RTX_NA_TILE_COST1 + RTX_NA_ALIGN((RTX_NOALLOC_MAX_TILES + 4) * sizeof(int)))
 #define RTX_NOALLOC_SCRATCH_BYTES (RTX_NA_PATH_STACK + (size_t)RTX_NOALLOC_MAX_BLOCKS * RTX_BLOCK * RTX_NOALLOC_GLOBAL_LEVELS * sizeof(float4))
-static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];   // 10.2 MB
+static __device__ __align__(256) unsigned char scratch[RTX_NOALLOC_SCRATCH_BYTES];   // 10.6 MB
 
 // ---------------------------------------------------------------------------------------------------
 // context
@@ -107,6 +108,15 @@ struct DevBuf {
         n = count;
         return RTX_OK;
     }
+    // the same, and memory that was allocated by the call is zeroed on `stream`, i.e. in order with the work the caller
+    // enqueues there next (a plain hipMemset runs on the default stream, which a non-blocking stream does not wait for)
+    int reserve_zeroed(size_t count, hipStream_t stream) {
+        if (count <= n && p) return RTX_OK;
+        const int rc = reserve(count);
+        if (rc) return rc;
+        if (hipMemsetAsync(p, 0, n * sizeof(T), stream) != hipSuccess) { rtx_set_error("hipMemsetAsync of a new buffer failed"); return RTX_E_DEVICE; }
+        return RTX_OK;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -119,7 +129,8 @@ struct FrameScratch {
     int* counters = nullptr;
     unsigned long long* work = nullptr;            // instrumented frames only
     float4* path_stack = nullptr;
-    unsigned char* tile_map = nullptr;
+    unsigned* tile_map = nullptr;
+    unsigned* prep_sync = nullptr;                 // ticket and done counters of the frame-start kernel (never reset)
     signed char* tile_class = nullptr;
     int* tile_list = nullptr;
     int* tile_cost[2] = {nullptr, nullptr};
@@ -129,8 +140,17 @@ struct HintState {
     int key[6] = {0, 0, 0, 0, 0, 0};   // W, H, tile_rows, rank, world, grid generation the cost map was recorded for
     rtx_camera cam{};                   // ... and the camera it was recorded under
     int cur = 0;                        // tile_cost[cur] was written by the last frame
+    int stamp[2] = {0, 0};              // the stamp its entries carry (shifted past the depth bits)
     bool valid = false;
 };
+// Where the never-reset words of a set of frame-start buffers stand: the stamp of the last frame that used the tile
+// map and the cost maps, and the values of the frame-start kernel's ticket and done counters.
+struct PrepState {
+    unsigned seq = 0;
+    unsigned ticket[3] = {0, 0, 0};
+    unsigned done[2] = {0, 0};
+};
+#define RTX_MAX_STAMP ((1u << (31 - RTX_COST_BITS)) - 2u)
 
 struct rtx_ctx {
     int device = 0;
@@ -163,7 +183,8 @@ struct rtx_ctx {
     DevBuf<int> pix0, hChild[RTX_MAX_LEVELS];
     DevBuf<float4> path_stack;
     DevBuf<float4> gen_stacks;    // generation pipeline: the request stacks and path slots of every wave of the launch
-    DevBuf<unsigned char> tile_map;
+    DevBuf<unsigned> tile_map, prep_sync;
+    PrepState prep;               // of the context's own frame-start buffers
     DevBuf<signed char> tile_class;
     DevBuf<int> tile_list, tile_cost[2];
     HintState hint;               // of the context's own cost maps
@@ -191,6 +212,7 @@ namespace {
 #define RTX_MAX_DEVICES 64
 std::mutex g_scratch_mutex;
 const rtx_ctx* g_scratch_user[RTX_MAX_DEVICES] = {};
+PrepState g_scratch_prep[RTX_MAX_DEVICES];      // of each device's scratch array (calls on one device do not overlap)
 // Makes `c` the scratch's user on its device; true if it already was.
 bool scratch_take_over(const rtx_ctx* c) {
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
@@ -855,7 +877,8 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         blocks = std::min(blocks, RTX_NOALLOC_MAX_BLOCKS);
         unsigned char* base = c->scratch;
         ws.counters = (int*)(base + RTX_NA_COUNTERS);
-        ws.tile_map = base + RTX_NA_TILE_MAP;
+        ws.tile_map = (unsigned*)(base + RTX_NA_TILE_MAP);
+        ws.prep_sync = (unsigned*)(base + RTX_NA_SYNC);
         ws.tile_class = (signed char*)(base + RTX_NA_TILE_CLASS);
         ws.tile_list = (int*)(base + RTX_NA_TILE_LIST);
         ws.tile_cost[0] = (int*)(base + RTX_NA_TILE_COST0);
@@ -940,12 +963,17 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     if (tile_cull) {
         if (!no_alloc) {
             const size_t n_slots = (size_t)tbx * ((nl + 7) / 8);
-            // + 16 bytes: the clear kernel writes whole 16-byte words
-            if ((rc = c->tile_map.reserve((size_t)tbx * tby + 16)) || (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
-                (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve(n_slots + 4)) ||
-                (rc = c->tile_cost[1].reserve(n_slots + 4)))
+            // (the tile map, the cost maps and the frame-start kernel's counters are never cleared per frame: they start as
+            // zeros, and a map that had to grow starts over -- its hint is then void)
+            const bool regrow = n_slots + 4 > c->tile_cost[0].n || n_slots + 4 > c->tile_cost[1].n;
+            if ((rc = c->tile_map.reserve_zeroed((size_t)tbx * tby + 4, st)) || (rc = c->prep_sync.reserve_zeroed(8, st)) ||
+                (rc = c->tile_list.reserve((size_t)n_row_blocks * f.nbx)) ||
+                (rc = c->tile_class.reserve((size_t)n_row_blocks * f.nbx)) || (rc = c->tile_cost[0].reserve_zeroed(n_slots + 4, st)) ||
+                (rc = c->tile_cost[1].reserve_zeroed(n_slots + 4, st)))
                 return rc;
+            if (regrow) c->hint.valid = false;
             ws.tile_map = c->tile_map.p;
+            ws.prep_sync = c->prep_sync.p;
             ws.tile_class = c->tile_class.p;
             ws.tile_list = c->tile_list.p;
             ws.tile_cost[0] = c->tile_cost[0].p;
@@ -996,10 +1024,81 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     const bool timed = stats != nullptr;
 
     hipEvent_t* ev = c->ev;
-    HIP_TRY(hipEventRecord(ev[0], st));              // frame time includes the fills
-    // one launch clears everything a frame starts from; caller buffers whose size or address is not a multiple of 16
-    // bytes fall back to memsets
-    {
+    HIP_TRY(hipEventRecord(ev[0], st));              // frame time includes the start of the frame
+    if (tile_cull) {
+        // Persistent kernel over the tiles that can see geometry: ONE launch before the frame kernel zeroes the counters,
+        // marks and classifies the tiles and writes the list (k_frame_prep); the frame kernel itself writes the miss
+        // colour over the blocks it does not trace.  Nothing is cleared per frame: the tile map and the cost maps hold
+        // stamps that differ from frame to frame.
+        PrepState* ps = no_alloc ? &g_scratch_prep[c->device < RTX_MAX_DEVICES ? c->device : 0] : &c->prep;
+        std::unique_lock<std::mutex> scratch_lock(g_scratch_mutex, std::defer_lock);
+        if (no_alloc) scratch_lock.lock();
+        if (ps->seq >= RTX_MAX_STAMP) {
+            // the stamps start over (after 2^26 frames): the maps go back to zeros, on the frame's stream
+            HIP_TRY(hipMemsetAsync(ws.tile_map, 0, (size_t)tbx * tby * sizeof(unsigned), st));
+            for (int k = 0; k < 2; k++) HIP_TRY(hipMemsetAsync(ws.tile_cost[k], 0, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), st));
+            ps->seq = 0;
+            hint->valid = false;
+        }
+        const unsigned stamp = ++ps->seq;
+        // the frame kernel fills what it does not trace when every 16-byte store of the fill is aligned; otherwise the
+        // buffers are cleared here, as for the pipelines without a tile list
+#ifndef RT_KERNEL_FILL
+#define RT_KERNEL_FILL 1
+#endif
+        const bool fill_ok = RT_KERNEL_FILL && p->width % 4 == 0 && ((uintptr_t)d_rgb & 15u) == 0 && (!d_ids || ((uintptr_t)d_ids & 15u) == 0);
+        if (!fill_ok) {
+            HIP_TRY(hipMemsetAsync(d_rgb, 0, pixels * 3 * sizeof(float), st));
+            if (d_ids) HIP_TRY(hipMemsetAsync(d_ids, 0xff, pixels * sizeof(int32_t), st));
+        }
+        // the map this frame records its per-block path depths into (the other one orders this frame's list)
+        hint->cur ^= 1;
+        // the previous frame's per-block path depths order this frame's list if they were recorded for the same
+        // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
+        const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
+        const bool feedback = hint->valid && memcmp(key, hint->key, sizeof key) == 0 && !(p->flags & RTX_RENDER_NO_TILE_HINT);
+        // a tile takes the deepest class recorded within hint_radius tiles around it: one tile allows for a camera
+        // that moved a little; the very same camera needs no allowance (4K frame of scene7: 2.08 against 2.19 ms)
+        f.hint_radius = feedback && memcmp(cam, &hint->cam, sizeof *cam) == 0 ? 0 : 1;
+        hint->cam = *cam;
+        f.tile_cost = ws.tile_cost[hint->cur];
+        f.cost_stamp = (int)(stamp << RTX_COST_BITS);
+        hint->stamp[hint->cur] = f.cost_stamp;
+        memcpy(hint->key, key, sizeof key);
+        hint->valid = true;
+        f.fill_cls = fill_ok ? ws.tile_class : nullptr;
+        f.fill_window_row_blocks = n_row_blocks;
+
+        PrepArgs a;
+        memset(&a, 0, sizeof a);
+        a.f = f;
+        a.g = c->dgrid;
+        a.occupied_cells = c->ocell.p;
+        a.pad = c->fine_pad;
+        a.n_occ = (int)c->ginfo.n_occupied_fine_cells;
+        a.tby = tby;
+        a.tile_map = ws.tile_map;
+        a.stamp = stamp;
+        a.n_row_blocks = n_row_blocks;
+        a.prev_cost = feedback ? ws.tile_cost[hint->cur ^ 1] : nullptr;
+        a.prev_stamp = hint->stamp[hint->cur ^ 1];
+        a.cls = ws.tile_class;
+        a.tile_list = ws.tile_list;
+        a.sync = ws.prep_sync;
+        a.work = count ? ws.work : nullptr;
+        const int n_blocks_window = n_row_blocks * f.nbx;
+        a.n_chunks[0] = 1 + (a.n_occ + 255) / 256;              // (chunk 0 zeroes the counters)
+        a.n_chunks[1] = a.n_chunks[2] = (n_blocks_window + 255) / 256;
+        const int prep_blocks = std::max(1, std::min(c->n_cus, std::max(a.n_chunks[0], a.n_chunks[1])));
+        for (int k = 0; k < 3; k++) a.ticket_base[k] = ps->ticket[k];
+        for (int k = 0; k < 2; k++) a.done_base[k] = ps->done[k];
+        hipLaunchKernelGGL(k_frame_prep, dim3(prep_blocks), dim3(256), 0, st, a);
+        // every workgroup draws one ticket beyond a phase's chunks; every chunk of the first two phases is reported once
+        for (int k = 0; k < 3; k++) ps->ticket[k] += (unsigned)(a.n_chunks[k] + prep_blocks);
+        for (int k = 0; k < 2; k++) ps->done[k] += (unsigned)a.n_chunks[k];
+    } else {
+        // one launch clears everything a frame starts from; caller buffers whose size or address is not a multiple of 16
+        // bytes fall back to memsets
         ClearRanges cr;
         memset(&cr, 0, sizeof cr);
         bool clear_overflow = false;
@@ -1018,40 +1117,11 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
         }
         add(ws.counters, CNT_TOTAL * sizeof(int), 0u);
         if (count) add(ws.work, 24 * sizeof(unsigned long long), 0u);
-        if (tile_cull) {
-            // the map this frame records its per-block path depths into (the other one orders this frame's list)
-            hint->cur ^= 1;
-            add(ws.tile_map, (size_t)tbx * tby, 0u);
-            add(ws.tile_cost[hint->cur], (size_t)tbx * ((nl + 7) / 8) * sizeof(int), 0u);
-        }
         if (clear_overflow) { rtx_set_error("render: more ranges to clear than the clear kernel takes"); return RTX_E_STATE; }
         long long total = 0;
         for (int k = 0; k < cr.n; k++) total += cr.words[k];
         const int clear_blocks = (int)std::min<long long>((total + 255) / 256, (long long)c->n_cus * 16);
         hipLaunchKernelGGL(k_frame_clear, dim3(std::max(clear_blocks, 1)), dim3(256), 0, st, cr);
-    }
-    if (tile_cull) {
-        const int n_occ = (int)c->ginfo.n_occupied_fine_cells;
-        if (n_occ > 0)
-            hipLaunchKernelGGL(k_tile_mark, dim3((n_occ + 255) / 256), dim3(256), 0, st, f.cam, c->dgrid, (const int*)c->ocell.p, c->fine_pad,
-                               n_occ, tbx, tby, ws.tile_map, ws.counters);
-        // the previous frame's per-block path depths order this frame's list if they were recorded for the same
-        // image geometry, rank split and grid (the camera may have moved: the order is a hint, never a result)
-        const int key[6] = {p->width, p->height, tile_rows, rank, world, c->grid_generation};
-        const bool feedback = hint->valid && memcmp(key, hint->key, sizeof key) == 0 && !(p->flags & RTX_RENDER_NO_TILE_HINT);
-        const int* prev_cost = feedback ? ws.tile_cost[hint->cur ^ 1] : nullptr;
-        // a tile takes the deepest class recorded within hint_radius tiles around it: one tile allows for a camera
-        // that moved a little; the very same camera needs no allowance (4K frame of scene7: 2.08 against 2.19 ms)
-        f.hint_radius = feedback && memcmp(cam, &hint->cam, sizeof *cam) == 0 ? 0 : 1;
-        hint->cam = *cam;
-        f.tile_cost = ws.tile_cost[hint->cur];
-        memcpy(hint->key, key, sizeof key);
-        hint->valid = true;
-        const int n_blocks_window = n_row_blocks * f.nbx;
-        hipLaunchKernelGGL(k_tile_classify, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
-                           (const unsigned char*)ws.tile_map, prev_cost, ws.tile_class);
-        hipLaunchKernelGGL(k_tile_fill, dim3((n_blocks_window + 255) / 256), dim3(256), 0, st, f, n_row_blocks,
-                           (const signed char*)ws.tile_class, ws.tile_list);
     }
     HIP_TRY(hipEventRecord(ev[3], st));              // start of the kernels proper
     if (!level_queues) {

@@ -17,7 +17,8 @@ struct DevCamera {
 #define CNT_SHADE_CUR 32
 #define CNT_RESOLVE_CUR 48
 #define CNT_TILES 64        // 8x8 pixel tiles the frame kernel traces (tile list)
-#define CNT_TILES_ALL 65    // set when a fine cell's screen footprint was too large or undefined: every tile is traced
+#define CNT_TILES_ALL 65    // holds the frame's stamp when a fine cell's screen footprint was too large or undefined: every tile
+                            // is traced (never cleared: a value other than this frame's stamp means "not set")
 #define CNT_CLASS 66        // 8 counters: tiles per scheduling class; 74..81: fill cursors per class
 #define CNT_ABORT 82        // set by a wave of the frame kernel that reached the round limit
 #define CNT_PIXELS 83       // pixels whose camera ray the frame kernel walked
@@ -34,7 +35,14 @@ struct DevFrame {
     const int* tile_list;          // persistent kernel, optional: the 8x8 blocks to trace, (row block << 16) | column block,
                                    // their number in counters[CNT_TILES]; null = every block of the window
     int* tile_cost;                // with tile_list: deepest path level seen per 8x8 block this frame (+2), indexed
-                                   // row block * tbx + column block; feeds the order of the next frame's list
+                                   // row block * tbx + column block; feeds the order of the next frame's list.  An entry
+                                   // is cost_stamp | depth: stamps grow from frame to frame, so a frame's entries beat
+                                   // whatever older frames left there and the map is never cleared
+    int cost_stamp;                // this frame's stamp, shifted past the depth bits (RTX_COST_BITS)
+    const signed char* fill_cls;   // non-null: the frame kernel itself writes the miss colour (and id -1) over the 8x8
+                                   // blocks it does not trace -- every block outside the traced window and every block
+                                   // of the window whose class here is negative
+    int fill_window_row_blocks;    // row blocks of the traced window (rows of fill_cls, nbx entries each)
     int tbx;                       // 8-pixel column blocks per image row
     int hint_radius;               // tiles around a tile whose recorded depths count for its class
     int max_depth;
@@ -71,6 +79,71 @@ struct DevFrame {
 };
 
 __device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
+
+#define RTX_COST_BITS 5            // depth + 2 <= 17 fits; the stamp takes the bits above
+
+// deepest level of a finished path, recorded for the 8x8 block of its pixel (scheduling hint of the next frame)
+__device__ __forceinline__ void record_tile_depth(const DevFrame& f, int tslot, int depth_plus_2) {
+    const int v = f.cost_stamp | depth_plus_2;
+    if (f.tile_cost && f.tile_cost[tslot] < v) atomicMax(f.tile_cost + tslot, v);
+}
+
+// The miss colour (src/main.cpp:104-106 of the reference tree: no hit, colour 0) and the id -1 over every 8x8 block of
+// this rank's rows that the frame kernel does not trace, written by the frame kernel's own waves before they start
+// tracing.  Wave `wave_global` of `n_waves` takes the runs of 64 consecutive blocks (row block major) numbered
+// wave_global, wave_global + n_waves, ...: one lane looks up whether each block of the run is traced, and the wave then
+// writes the run row by row -- 64 blocks x 96 bytes of colour are 384 consecutive 16-byte chunks of an image row, six
+// store instructions of 64 lanes each, every lane skipping the chunks of traced blocks and of pixels beyond the image
+// width (a run that reaches the end of a row block continues in the next one).  The host only asks for this when
+// the image width is a multiple of 4 pixels and both buffers are 16-byte aligned, which makes every chunk aligned.
+__device__ __forceinline__ void fill_untraced_blocks(const DevFrame& f, int wave_global, int n_waves) {
+    if (!f.fill_cls) return;
+    const int lane = wave_lane();
+    const int tbx = f.tbx;
+    const int n_blocks = ((f.n_local_rows + 7) >> 3) * tbx;
+    const int wrb0 = f.lr0 >> 3;
+    for (int b0 = wave_global * 64; b0 < n_blocks; b0 += n_waves * 64) {
+        const int rb0 = b0 / tbx, bx0 = b0 - rb0 * tbx;     // (wave-uniform) first block of the run
+        bool fill = false;
+        {
+            int rb = rb0, bx = bx0 + lane;
+            while (bx >= tbx) { bx -= tbx; rb++; }
+            if (b0 + lane < n_blocks) {
+                const int wr = rb - wrb0, wc = bx - f.bx0;
+                const bool in_window = wr >= 0 && wr < f.fill_window_row_blocks && wc >= 0 && wc < f.nbx;
+                fill = !in_window || f.fill_cls[wr * f.nbx + wc] < 0;
+            }
+        }
+        const unsigned long long todo = __ballot(fill);
+        if (todo == 0) continue;
+        const int row_bytes = 12 * f.W;
+#pragma unroll 1
+        for (int row = 0; row < 8; row++) {
+#pragma unroll
+            for (int part = 0; part < 6; part++) {           // colour: chunk c of the run's 384 per row
+                const int c = 64 * part + lane;
+                const int blk = c / 6, q = c - 6 * blk;
+                int rb = rb0, bx = bx0 + blk;
+                while (bx >= tbx) { bx -= tbx; rb++; }
+                const int lr = 8 * rb + row, at = 96 * bx + 16 * q;
+                if (((todo >> blk) & 1ull) && lr < f.n_local_rows && at < row_bytes)
+                    *(float4*)((char*)f.rgb + (size_t)lr * row_bytes + at) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (f.ids) {
+#pragma unroll
+                for (int part = 0; part < 2; part++) {       // ids: 64 blocks x 32 bytes are 128 chunks per row
+                    const int c = 64 * part + lane;
+                    const int blk = c >> 1, h = c & 1;
+                    int rb = rb0, bx = bx0 + blk;
+                    while (bx >= tbx) { bx -= tbx; rb++; }
+                    const int lr = 8 * rb + row, px = 8 * bx + 4 * h;
+                    if (((todo >> blk) & 1ull) && lr < f.n_local_rows && px < f.W)
+                        *(int4*)(f.ids + (size_t)lr * f.W + px) = make_int4(-1, -1, -1, -1);
+                }
+            }
+        }
+    }
+}
 
 // One 64-ray chunk per call, handed out through an atomic cursor so that waves that drew cheap rays
 // come back for more.  Every wave reaches base >= n eventually because the cursor only grows.

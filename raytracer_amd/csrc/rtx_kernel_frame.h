@@ -98,6 +98,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
     unsigned long long log_start = 0, log_exhausted = 0;
     int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0, log_tasks = 0;
     if (COUNT) log_start = wall_clock64();
+    fill_untraced_blocks(f, (int)blockIdx.x * (RTX_BLOCK / 64) + wave, (int)gridDim.x * (RTX_BLOCK / 64));
 
     for (;;) {
         const bool alive = pix != -1;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
                 fu.rgb[3 * pix] = C.x;
                 fu.rgb[3 * pix + 1] = C.y;
                 fu.rgb[3 * pix + 2] = C.z;
-                if (fu.tile_cost && fu.tile_cost[tslot] < top + 2) atomicMax(fu.tile_cost + tslot, top + 2);
+                record_tile_depth(fu, tslot, top + 2);
                 if (COUNT) log_deepest = max(log_deepest, top + 1);
                 pix = -1;
                 phase = 0;
@@ -362,23 +363,74 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame(DevScene sc, DevGrid
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Screen tiles that can see geometry (nested search, persistent kernel).  A camera ray can only hit a primitive
-// inside an occupied fine cell (every point of a primitive lies in a fine cell that references it), so an 8x8 pixel
-// tile outside the projection of every occupied fine cell returns the miss colour for all its pixels
-// (src/main.cpp:104-106) and is left to the fills.  k_tile_mark projects the eight corners of every occupied fine
-// cell (grown by the binning margin) and marks the tiles of the bounding rectangle grown by two pixels; a cell
-// with a corner beside or behind the eye, or one covering more than 1024 tiles, raises the "every tile" flag
-// instead.  k_tile_list then collects this rank's marked blocks of the traced window.
+// Start of a frame of the persistent kernels in ONE launch (k_frame_prep): zero the frame's counters, find the
+// screen tiles that can see geometry, put them into scheduling classes and write the list the frame kernel draws from.
+//
+// A camera ray can only hit a primitive inside an occupied fine cell (every point of a primitive lies in a fine cell
+// that references it), so an 8x8 pixel tile outside the projection of every occupied fine cell returns the miss colour
+// for all its pixels (src/main.cpp:104-106) and is left to the frame kernel's fill.  Three phases:
+//   mark      projects the eight corners of every occupied fine cell (grown by the binning margin) and marks the tiles
+//             of the bounding rectangle grown by two pixels; a cell with a corner beside or behind the eye, or one
+//             covering more than 1024 tiles, raises the "every tile" flag instead.  A marked tile holds the frame's
+//             stamp in the tile map; stamps differ from frame to frame, so the map is never cleared.  One chunk of
+//             this phase zeroes the frame's counters.
+//   classify  one lane per 8x8 block of this rank's traced window (rows are local rows; a block's eight rows may come
+//             from different global tiles when the rank split is not in multiples of eight rows): blocks that can see
+//             geometry get one of eight classes by the deepest path the block -- or a block within hint_radius of it --
+//             produced in the previous frame of the same geometry (0 = unknown), and the classes are counted;
+//   list      writes the list with the deepest class first, so that the long dependent chains of a frame start early
+//             and the frame does not end on them.
+// Phases follow each other inside the launch without a grid-wide barrier of resident workgroups: the work of a phase
+// is cut into chunks of 256 items which the launch's workgroups draw from a ticket counter, a workgroup that finds a
+// phase's tickets used up waits until that phase's chunks are all reported done and moves on.  Whoever holds a
+// ticket is running, so the wait always ends -- also when the GPU is full of other launches' workgroups and only a
+// few of this launch's get to run (any one of them can do all the work).  The ticket and done counters are never
+// reset either: the host passes the values they had before the launch.
+// What one phase hands to the next crosses compute units and their caches inside the launch.  No cache-wide fence is
+// used for that (a write-back of a whole L2 per chunk is dear, and dearer still beside frame kernels that are filling
+// their frames): every word a later phase reads -- tile-map stamps, the zeroed counters, the class totals -- is
+// written by a store or an atomic that goes through to memory and read by a load that bypasses the reader's caches,
+// every storing wave waits for its stores before its workgroup reports a chunk, and a workgroup reads only after its
+// polling lane has seen every chunk reported.  The class of a block is computed twice, by the phase that counts and
+// by the phase that lists (cheap, and the same inputs), instead of being handed over.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_tile_mark(DevCamera cam, DevGrid g, const int* occupied_cells, float pad, int n_occupied, int tbx, int tby,
-                            unsigned char* tile_map, int* counters) {
-    const int o = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (o >= n_occupied) return;
-    const int i = occupied_cells[o];                      // fine cell number: block * cells per block + local
+// word that another compute unit of the same launch reads / wrote: write-through store, cache-bypassing load
+__device__ __forceinline__ void store_through(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_through(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned load_through(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int load_through(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct PrepArgs {
+    DevFrame f;
+    DevGrid g;
+    const int* occupied_cells;     // fine cell number of every occupied fine cell
+    float pad;                     // margin the fine lists were binned with
+    int n_occ;
+    int tby;                       // 8-pixel row blocks of the whole image (f.tbx column blocks)
+    unsigned* tile_map;            // per 8x8 tile of the image: == stamp if the tile may see geometry this frame
+    unsigned stamp;
+    int n_row_blocks;              // row blocks of this rank's traced window
+    const int* prev_cost;          // the previous frame's per-block depths (entries stamped prev_stamp), or null
+    int prev_stamp;                // (already shifted past the depth bits)
+    signed char* cls;              // per block of the window: class, -1 = not traced
+    int* tile_list;
+    unsigned* sync;                // [0..2] tickets drawn per phase, [3..4] chunks done of the first two phases
+    unsigned ticket_base[3], done_base[2];
+    int n_chunks[3];
+    unsigned long long* work;      // instrumented frames: the 24 work counters (zeroed here), else null
+};
+
+__device__ __forceinline__ void prep_mark(const PrepArgs& a, int o) {
+    if (o >= a.n_occ) return;
+    const DevGrid& g = a.g;
+    const DevCamera& cam = a.f.cam;
+    const int tbx = a.f.tbx, tby = a.tby;
+    const int i = a.occupied_cells[o];                    // fine cell number: block * cells per block + local
     const int cell = i / g.cpb, local = i - cell * g.cpb;
     const int k = g.sub;
     const int cx = cell % g.rx, cy = (cell / g.rx) % g.ry, cz = cell / (g.rx * g.ry);
     const int lx = local % k, ly = (local / k) % k, lz = local / (k * k);
+    const double pad = a.pad;
     const double lo[3] = {(double)g.lo.x + (double)(cx * k + lx) * g.fcell.x - pad, (double)g.lo.y + (double)(cy * k + ly) * g.fcell.y - pad,
                           (double)g.lo.z + (double)(cz * k + lz) * g.fcell.z - pad};
     const double hi[3] = {lo[0] + g.fcell.x + 2.0 * pad, lo[1] + g.fcell.y + 2.0 * pad, lo[2] + g.fcell.z + 2.0 * pad};
@@ -390,90 +442,131 @@ __global__ void k_tile_mark(DevCamera cam, DevGrid g, const int* occupied_cells,
         const double depth = -(dx * cam.w.x + dy * cam.w.y + dz * cam.w.z);
         const double extent = fabs(dx) + fabs(dy) + fabs(dz);
         if (!(depth > 1e-3 * extent) || !(depth > 0)) { undefined = true; break; }
-        const double a = (dx * cam.u.x + dy * cam.u.y + dz * cam.u.z) / depth;
-        const double b = (dx * cam.v.x + dy * cam.v.y + dz * cam.v.z) / depth;
-        const double sx = a / cam.tanx * cam.halfW + cam.halfW - 0.5;      // inverse of Camera::getRayAt (src/geometries.h:339-351)
-        const double sy = cam.halfH - 0.5 - b / cam.tany * cam.halfH;
+        const double u = (dx * cam.u.x + dy * cam.u.y + dz * cam.u.z) / depth;
+        const double v = (dx * cam.v.x + dy * cam.v.y + dz * cam.v.z) / depth;
+        const double sx = u / cam.tanx * cam.halfW + cam.halfW - 0.5;      // inverse of Camera::getRayAt (src/geometries.h:339-351)
+        const double sy = cam.halfH - 0.5 - v / cam.tany * cam.halfH;
         if (!(sx == sx) || !(sy == sy)) { undefined = true; break; }
         xmin = fmin(xmin, sx); xmax = fmax(xmax, sx);
         ymin = fmin(ymin, sy); ymax = fmax(ymax, sy);
     }
-    if (undefined) { counters[CNT_TILES_ALL] = 1; return; }
+    if (undefined) { store_through(a.f.counters + CNT_TILES_ALL, (int)a.stamp); return; }
     const double margin = 2.0;
     if (xmax + margin < 0.0 || ymax + margin < 0.0 || xmin - margin > 8.0 * tbx || ymin - margin > 8.0 * tby) return;   // off screen
     const int tx0 = (int)fmax(0.0, floor((xmin - margin) / 8.0)), tx1 = (int)fmin((double)(tbx - 1), floor((xmax + margin) / 8.0));
     const int ty0 = (int)fmax(0.0, floor((ymin - margin) / 8.0)), ty1 = (int)fmin((double)(tby - 1), floor((ymax + margin) / 8.0));
     if (tx1 < tx0 || ty1 < ty0) return;
-    if ((long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) { counters[CNT_TILES_ALL] = 1; return; }
+    if ((long long)(tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 1024) { store_through(a.f.counters + CNT_TILES_ALL, (int)a.stamp); return; }
     for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) tile_map[ty * tbx + tx] = 1;
+        for (int tx = tx0; tx <= tx1; tx++) store_through(a.tile_map + ty * tbx + tx, a.stamp);
 }
 
-// One lane per 8x8 block of this rank's traced window (rows are local rows; a block's eight rows may come from
-// different global tiles when the rank split is not in multiples of eight rows).  Blocks that can see geometry are
-// put into eight scheduling classes by the deepest path the block produced in the previous frame of the same
-// geometry (0 = unknown): k_tile_classify counts the classes, k_tile_fill writes the list with the deepest class
-// first, so that the long dependent chains of a frame start early and the frame does not end on them.
-__device__ __forceinline__ bool tile_block(const DevFrame& f, int i, int n_row_blocks, int tbx, const unsigned char* tile_map,
-                                           int& rb, int& bx) {
-    if (i >= n_row_blocks * f.nbx) return false;
-    rb = f.lr0 / 8 + i / f.nbx;
-    bx = f.bx0 + i % f.nbx;
-    bool take = f.counters[CNT_TILES_ALL] != 0;
+// Class of block i of the window: -1 = sees no geometry (not traced), else one of eight scheduling classes by the
+// deepest path the block -- or a block within hint_radius of it: a camera that moved a little still finds its deep
+// tiles -- produced in the previous frame (0 = unknown).
+__device__ __forceinline__ int prep_class(const PrepArgs& a, int i) {
+    const DevFrame& f = a.f;
+    if (i >= a.n_row_blocks * f.nbx) return -1;
+    const int rb = f.lr0 / 8 + i / f.nbx;                 // row block (of local rows) and column block
+    const int bx = f.bx0 + i % f.nbx;
+    bool take = load_through(f.counters + CNT_TILES_ALL) == (int)a.stamp;
     for (int r = 0; r < 8 && !take; r++) {
         const int lr = 8 * rb + r;
         if (lr >= f.n_local_rows) break;
         const int tile = lr / f.tile_rows;
         const int y = (f.rank + tile * f.world) * f.tile_rows + (lr - tile * f.tile_rows);
-        take = tile_map[(y >> 3) * tbx + bx] != 0;
+        take = load_through(a.tile_map + (y >> 3) * f.tbx + bx) == a.stamp;
     }
-    return take;
-}
-__global__ __launch_bounds__(256) void k_tile_classify(DevFrame f, int n_row_blocks, const unsigned char* tile_map, const int* prev_cost,
-                                                       signed char* cls) {
-    __shared__ int cnt[8];
-    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    int rb = 0, bx = 0;
-    const bool take = tile_block(f, i, n_row_blocks, f.tbx, tile_map, rb, bx);
-    int c = -1;
-    if (take) {
-        c = 0;
-        if (prev_cost) {
-            // the deepest class within `hint_radius` tiles: a camera that moved a little still finds its deep tiles
-            const int nrb = (f.n_local_rows + 7) / 8, R = f.hint_radius;
-            for (int dy = -R; dy <= R; dy++)
-                for (int dx = -R; dx <= R; dx++) {
-                    const int y = rb + dy, x = bx + dx;
-                    if (y >= 0 && y < nrb && x >= 0 && x < f.tbx) c = max(c, prev_cost[y * f.tbx + x]);
+    if (!take) return -1;
+    int c = 0;
+    if (a.prev_cost) {
+        const int nrb = (f.n_local_rows + 7) / 8, R = f.hint_radius;
+        for (int dy = -R; dy <= R; dy++)
+            for (int dx = -R; dx <= R; dx++) {
+                const int y = rb + dy, x = bx + dx;
+                if (y >= 0 && y < nrb && x >= 0 && x < f.tbx) {
+                    const int v = a.prev_cost[y * f.tbx + x];
+                    if ((v & ~((1 << RTX_COST_BITS) - 1)) == a.prev_stamp) c = max(c, v & ((1 << RTX_COST_BITS) - 1));
                 }
-            c = min(c, 7);
-        }
+            }
+        c = min(c, 7);
     }
-    if (i < n_row_blocks * f.nbx) cls[i] = (signed char)c;
-    if (c >= 0) atomicAdd(&cnt[c], 1);
-    __syncthreads();
-    if (threadIdx.x < 8 && cnt[threadIdx.x]) {
-        atomicAdd(f.counters + CNT_CLASS + threadIdx.x, cnt[threadIdx.x]);
-        atomicAdd(f.counters + CNT_TILES, cnt[threadIdx.x]);
-    }
+    return c;
 }
-__global__ __launch_bounds__(256) void k_tile_fill(DevFrame f, int n_row_blocks, const signed char* cls, int* tile_list) {
+
+__global__ __launch_bounds__(256) void k_frame_prep(PrepArgs a) {
+    __shared__ unsigned s_ticket;
     __shared__ int cnt[8], base[8], rank[8];
-    if (threadIdx.x < 8) { cnt[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
-    __syncthreads();
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int n = n_row_blocks * f.nbx;
-    const int c = i < n ? (int)cls[i] : -1;
-    if (c >= 0) atomicAdd(&cnt[c], 1);
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int k = (int)threadIdx.x;
-        int offset = 0;                                       // classes above k come first in the list
-        for (int j = k + 1; j < 8; j++) offset += f.counters[CNT_CLASS + j];
-        base[k] = offset + (cnt[k] ? atomicAdd(f.counters + CNT_CLASS + 8 + k, cnt[k]) : 0);
+    const int tid = (int)threadIdx.x;
+    const DevFrame& f = a.f;
+    // the next chunk of a phase, or a number >= the phase's chunks when they are used up (every workgroup draws exactly
+    // one such ticket per phase, which is how the host knows where the counters stand after the launch)
+    const auto draw = [&](int phase) -> int {
+        __syncthreads();                                  // everyone is done with s_ticket and the chunk before
+        if (tid == 0) s_ticket = atomicAdd(a.sync + phase, 1u) - a.ticket_base[phase];
+        __syncthreads();
+        return (int)min(s_ticket, 0x7fffffffu);
+    };
+    // a chunk is reported done when every wave's stores of it have gone through
+    const auto chunk_done = [&](int phase) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) atomicAdd(a.sync + 3 + phase, 1u);
+    };
+    const auto wait_for = [&](int phase) {
+        if (tid == 0) {
+            while (load_through(a.sync + 3 + phase) - a.done_base[phase] < (unsigned)a.n_chunks[phase]) __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    };
+
+    // ---- mark (chunk 0 zeroes the frame's counters instead) ----------------------------------------------------------
+    for (;;) {
+        const int t = draw(0);
+        if (t >= a.n_chunks[0]) break;
+        if (t == 0) {
+            for (int i = tid; i < CNT_TOTAL; i += 256)
+                if (i != CNT_TILES_ALL) store_through(f.counters + i, 0);
+            if (a.work && tid < 24) a.work[tid] = 0ull;
+        } else {
+            prep_mark(a, (t - 1) * 256 + tid);
+        }
+        chunk_done(0);
     }
-    __syncthreads();
-    if (c >= 0) tile_list[base[c] + atomicAdd(&rank[c], 1)] = ((f.lr0 / 8 + i / f.nbx) << 16) | (f.bx0 + i % f.nbx);
+    wait_for(0);
+    // ---- classify ----------------------------------------------------------------------------------------------------
+    for (;;) {
+        const int t = draw(1);
+        if (t >= a.n_chunks[1]) break;
+        if (tid < 8) cnt[tid] = 0;
+        __syncthreads();
+        const int c = prep_class(a, t * 256 + tid);
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+        __syncthreads();
+        if (tid < 8 && cnt[tid]) {
+            atomicAdd(f.counters + CNT_CLASS + tid, cnt[tid]);
+            atomicAdd(f.counters + CNT_TILES, cnt[tid]);
+        }
+        chunk_done(1);
+    }
+    wait_for(1);
+    // ---- list --------------------------------------------------------------------------------------------------------
+    for (;;) {
+        const int t = draw(2);
+        if (t >= a.n_chunks[2]) break;
+        if (tid < 8) { cnt[tid] = 0; rank[tid] = 0; }
+        __syncthreads();
+        const int i = t * 256 + tid;
+        const int c = prep_class(a, i);
+        if (i < a.n_row_blocks * f.nbx) a.cls[i] = (signed char)c;          // (read by the frame kernel's fill)
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+        __syncthreads();
+        if (tid < 8) {
+            int offset = 0;                                       // classes above this one come first in the list
+            for (int j = tid + 1; j < 8; j++) offset += load_through(f.counters + CNT_CLASS + j);
+            base[tid] = offset + (cnt[tid] ? atomicAdd(f.counters + CNT_CLASS + 8 + tid, cnt[tid]) : 0);
+        }
+        __syncthreads();
+        if (c >= 0) a.tile_list[base[c] + atomicAdd(&rank[c], 1)] = ((f.lr0 / 8 + i / f.nbx) << 16) | (f.bx0 + i % f.nbx);
+    }
 }

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
     int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0;
     if (COUNT) log_start = wall_clock64();
     const unsigned long long below = (1ull << lane) - 1ull;
+    fill_untraced_blocks(f, (int)blockIdx.x * (RTX_BLOCK / 64) + wave, (int)gridDim.x * (RTX_BLOCK / 64));
 
     for (;;) {
         // ---- which generation ----------------------------------------------------------------------------------
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
                     fu.rgb[3 * pix] = 0.0f;
                     fu.rgb[3 * pix + 1] = 0.0f;
                     fu.rgb[3 * pix + 2] = 0.0f;
-                    if (fu.tile_cost && fu.tile_cost[tslot] < 1) atomicMax(fu.tile_cost + tslot, 1);
+                    record_tile_depth(fu, tslot, 1);
                 } else {
                     delta = (level << 16) - 1;              // terms of levels 0 .. level - 1
                 }
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
             fu.rgb[3 * where.x] = C.x;
             fu.rgb[3 * where.x + 1] = C.y;
             fu.rgb[3 * where.x + 2] = C.z;
-            if (fu.tile_cost && fu.tile_cost[where.y] < top + 2) atomicMax(fu.tile_cost + where.y, top + 2);
+            record_tile_depth(fu, where.y, top + 2);
             if (COUNT) log_deepest = max(log_deepest, top + 1);
             free_slot[wave][n_free + __popcll(mask_f & below)] = (unsigned short)slot;
         }

@@ -414,6 +414,37 @@ def test_render_device_on_a_side_stream_with_torch_memory(renderer):
     assert np.array_equal(again.view(np.int32), want.view(np.int32))
 
 
+def test_first_frames_of_fresh_contexts_on_side_streams(renderer):
+    """A fresh context's first frame allocates its frame-start buffers and must zero them in the order of the frame's
+    own stream: rendered on non-blocking side streams into memory full of other values, three contexts at once, then
+    again at a larger size (the buffers grow) -- every pixel equal to the session context's frame."""
+    sr, _ = load(renderer, "scene4-specular")
+    want = {}
+    for (W, H) in ((320, 240), (648, 488)):
+        want[(W, H)] = renderer.render(W, H, 5, want_ids=True)[:2]
+    fresh = [rt.Renderer(0) for _ in range(3)]
+    try:
+        streams = [torch.cuda.Stream() for _ in fresh]
+        for r in fresh:
+            r.set_scene(sr)
+            r.build_grid(15, 0)
+        for (W, H) in ((320, 240), (648, 488)):
+            rgb = [torch.full((H, W, 3), 5.0, dtype=torch.float32, device="cuda") for _ in fresh]
+            ids = [torch.full((H, W), 12345, dtype=torch.int32, device="cuda") for _ in fresh]
+            torch.cuda.synchronize()
+            for rep in range(2):
+                for k, r in enumerate(fresh):
+                    r.render_device(rgb[k].data_ptr(), ids[k].data_ptr(), W, H, stream=streams[k].cuda_stream, workgroups_per_cu=1 + rep)
+            torch.cuda.synchronize()
+            for k, r in enumerate(fresh):
+                r.frame_status()
+                assert np.array_equal(ids[k].cpu().numpy(), want[(W, H)][1]), (W, H, k)
+                assert np.array_equal(rgb[k].cpu().numpy().view(np.int32), want[(W, H)][0].view(np.int32)), (W, H, k)
+    finally:
+        for r in fresh:
+            r.close()
+
+
 def test_state_and_argument_errors():
     r = rt.Renderer(0)
     try:
