@@ -27,7 +27,7 @@
 //
 // Per wave in device memory (float4 units, see rtx_gen_wave_f4): S stack, 3 fields x RTX_GEN_CAP slots, structure of
 // arrays (field k of slot s at k * RTX_GEN_CAP + s, so a generation's pops and pushes are contiguous 1 KB accesses per
-// field); M stack, 2 fields; terms, n_levels per path slot.
+// field); M stack, 2 fields; pixel of every path slot; terms, n_levels per path slot.
 //   S request: field 0 = (P, material << 4 | level)   1 = (N, path slot)    2 = (incoming direction, -)
 //   M request: field 0 = (O, path slot << 4 | level)  1 = (R, -)
 //   term:      (L xyz of the level, material)
@@ -43,17 +43,19 @@
 #define RTX_GEN_PATHS 320
 // float4s of device memory per wave for frames of n_levels path levels
 __host__ __device__ constexpr size_t rtx_gen_wave_f4(int n_levels) {
-    return (size_t)RTX_GEN_CAP * (RTX_GEN_S_FIELDS + RTX_GEN_M_FIELDS) + (size_t)RTX_GEN_PATHS * (size_t)n_levels;
+    return (size_t)RTX_GEN_CAP * (RTX_GEN_S_FIELDS + RTX_GEN_M_FIELDS) + (size_t)RTX_GEN_PATHS / 2 + (size_t)RTX_GEN_PATHS * (size_t)n_levels;
 }
 
+#ifndef RT_GEN_WAVES_MIN
+#define RT_GEN_WAVES_MIN 0         // (development: hold the generation kernel's allocation to at least this many waves per SIMD)
+#endif
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
-__global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_levels) {
+__global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_GEN_WAVES_MIN)) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_levels) {
     __shared__ WaveLds lds[RTX_BLOCK / 64];
     __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
     // per path slot: low half = what is outstanding for the path, high half = 1 + its deepest level with a term (once
     // its chain has ended, 0 before)
     __shared__ int path_state[RTX_BLOCK / 64][RTX_GEN_PATHS];
-    __shared__ int2 path_pixel[RTX_BLOCK / 64][RTX_GEN_PATHS];        // local pixel index, 8x8 block of the cost map
     __shared__ unsigned short free_slot[RTX_BLOCK / 64][RTX_GEN_PATHS];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const Occupancy occ = stage_occupancy(g, occ_lds);
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
     int n_free = RTX_GEN_PATHS;                         // free path slots (wave-uniform): free_slot[0 .. n_free)
     float4* const qS = queues + (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * rtx_gen_wave_f4(n_levels);
     float4* const qM = qS + RTX_GEN_CAP * RTX_GEN_S_FIELDS;
-    float4* const terms = qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS;
+    int2* const path_pixel = (int2*)(qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS);   // per path slot: local pixel index, 8x8 block of the cost map
+    float4* const terms = qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS + RTX_GEN_PATHS / 2;
     WorkCounters wc = {};
 
     Walker<MODE> w;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
         if (begins) {
             slot = (int)free_slot[wave][n_free - 1 - __popcll(mask_b & below)];
             path_state[wave][slot] = 1;
-            path_pixel[wave][slot] = make_int2(pix, tslot);
+            path_pixel[slot] = make_int2(pix, tslot);
         }
         n_free -= __popcll(mask_b);
         wave_lds_sync();
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(RTX_BLOCK, WAVES) void k_frame_gen(DevScene sc, Dev
         const unsigned long long mask_f = __ballot(folds);
         if (folds) {
             const int top = (state >> 16) - 1;
-            const int2 where = path_pixel[wave][slot];
+            const int2 where = path_pixel[slot];
             f3 C = mk(0, 0, 0);
             for (int d = top; d >= 0; d--) {
                 const float4 s4 = terms[slot * n_levels + d];
