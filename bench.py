@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--sync-gather", "--one-frame-at-a-time", dest="sync_gather", action="store_true",
                     help="one frame in flight: every frame is rendered, gathered and assembled before the next one starts "
                          "(`value` then is the latency figure)")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="override the number of frames kept in flight (tuning runs)")
+    ap.add_argument("--workgroups-per-cu", type=int, default=0, help="... and the workgroups per CU of each frame's launch")
     ap.add_argument("--gather", choices=["f32", "u8"], default="f32",
                     help="what travels to rank 0: the float framebuffer (Image3f, the default) or the 8-bit image the "
                          "reference saves, converted on each GPU before the gather (a quarter of the bytes)")
@@ -180,6 +182,8 @@ def main():
     # CUs work on it, so at 8 ranks six frames with one workgroup per CU each run side by side (no gather: 0.33 ms per
     # frame against 0.51 with three frames, 0.75 with two).
     depth, wg_per_cu = _frames_in_flight(world, args.sync_gather, HW_QUEUES)
+    if args.frames_in_flight > 0 and not args.sync_gather:
+        depth, wg_per_cu = args.frames_in_flight, max(args.workgroups_per_cu, 1)
     renderers = [r]
     for _ in range(1, depth):
         extra = rt.Renderer(local_rank)
