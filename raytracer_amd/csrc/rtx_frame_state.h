@@ -90,25 +90,32 @@ __device__ __forceinline__ void record_tile_depth(const DevFrame& f, int tslot, 
 
 // The miss colour (src/main.cpp:104-106 of the reference tree: no hit, colour 0) and the id -1 over every 8x8 block of
 // this rank's rows that the frame kernel does not trace, written by the frame kernel's own waves before they start
-// tracing.  Wave `wave_global` of `n_waves` takes the runs of 64 consecutive blocks (row block major) numbered
-// wave_global, wave_global + n_waves, ...: one lane looks up whether each block of the run is traced, and the wave then
-// writes the run row by row -- 64 blocks x 96 bytes of colour are 384 consecutive 16-byte chunks of an image row, six
-// store instructions of 64 lanes each, every lane skipping the chunks of traced blocks and of pixels beyond the image
-// width (a run that reaches the end of a row block continues in the next one).  The host only asks for this when
-// the image width is a multiple of 4 pixels and both buffers are 16-byte aligned, which makes every chunk aligned.
+// tracing.  The unit of work is one image row of a run of 64 consecutive blocks: 384 consecutive 16-byte chunks of
+// colour (six store instructions of 64 lanes) and 128 of ids (two), every lane skipping the chunks of traced blocks and
+// of pixels beyond the image width.  Units are numbered along the rows, row after row, and wave w of n takes units w,
+// w + n, ...: at any time the waves of the launch write one contiguous band of the image.  (Eight rows of a run per wave
+// -- a block run at a time -- had 2000 waves write 6 KB pieces 46 KB apart all over the frame at once: memory pages
+// opened and closed for every piece, and a frame that is busy to its end lost 0.23 ms to it.)  One lane looks up
+// whether each block of the run is traced.  The host only asks for this when the image width is a multiple of 4 pixels
+// and both buffers are 16-byte aligned, which makes every chunk aligned.
+#ifndef RT_FILL_NO_STORES
+#define RT_FILL_NO_STORES 0        // (development: the fill's bookkeeping without its stores, to price the two apart)
+#endif
 __device__ __forceinline__ void fill_untraced_blocks(const DevFrame& f, int wave_global, int n_waves) {
     if (!f.fill_cls) return;
     const int lane = wave_lane();
     const int tbx = f.tbx;
-    const int n_blocks = ((f.n_local_rows + 7) >> 3) * tbx;
+    const int runs_per_row = (tbx + 63) >> 6;
+    const int n_units = f.n_local_rows * runs_per_row;
     const int wrb0 = f.lr0 >> 3;
-    for (int b0 = wave_global * 64; b0 < n_blocks; b0 += n_waves * 64) {
-        const int rb0 = b0 / tbx, bx0 = b0 - rb0 * tbx;     // (wave-uniform) first block of the run
+    const int row_bytes = 12 * f.W;
+    for (int u = wave_global; u < n_units; u += n_waves) {
+        const int lr = u / runs_per_row, bx0 = (u - lr * runs_per_row) << 6;    // (wave-uniform) row, first block of the run
+        const int rb = lr >> 3;
         bool fill = false;
         {
-            int rb = rb0, bx = bx0 + lane;
-            while (bx >= tbx) { bx -= tbx; rb++; }
-            if (b0 + lane < n_blocks) {
+            const int bx = bx0 + lane;
+            if (bx < tbx) {
                 const int wr = rb - wrb0, wc = bx - f.bx0;
                 const bool in_window = wr >= 0 && wr < f.fill_window_row_blocks && wc >= 0 && wc < f.nbx;
                 fill = !in_window || f.fill_cls[wr * f.nbx + wc] < 0;
@@ -116,30 +123,22 @@ __device__ __forceinline__ void fill_untraced_blocks(const DevFrame& f, int wave
         }
         const unsigned long long todo = __ballot(fill);
         if (todo == 0) continue;
-        const int row_bytes = 12 * f.W;
-#pragma unroll 1
-        for (int row = 0; row < 8; row++) {
 #pragma unroll
-            for (int part = 0; part < 6; part++) {           // colour: chunk c of the run's 384 per row
+        for (int part = 0; part < 6; part++) {               // colour: chunk c of the run's 384
+            const int c = 64 * part + lane;
+            const int blk = c / 6, q = c - 6 * blk;
+            const int at = 96 * (bx0 + blk) + 16 * q;
+            if (!RT_FILL_NO_STORES && ((todo >> blk) & 1ull) && at < row_bytes)
+                *(float4*)((char*)f.rgb + (size_t)lr * row_bytes + at) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        if (f.ids) {
+#pragma unroll
+            for (int part = 0; part < 2; part++) {           // ids: 64 blocks x 32 bytes are 128 chunks
                 const int c = 64 * part + lane;
-                const int blk = c / 6, q = c - 6 * blk;
-                int rb = rb0, bx = bx0 + blk;
-                while (bx >= tbx) { bx -= tbx; rb++; }
-                const int lr = 8 * rb + row, at = 96 * bx + 16 * q;
-                if (((todo >> blk) & 1ull) && lr < f.n_local_rows && at < row_bytes)
-                    *(float4*)((char*)f.rgb + (size_t)lr * row_bytes + at) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            if (f.ids) {
-#pragma unroll
-                for (int part = 0; part < 2; part++) {       // ids: 64 blocks x 32 bytes are 128 chunks per row
-                    const int c = 64 * part + lane;
-                    const int blk = c >> 1, h = c & 1;
-                    int rb = rb0, bx = bx0 + blk;
-                    while (bx >= tbx) { bx -= tbx; rb++; }
-                    const int lr = 8 * rb + row, px = 8 * bx + 4 * h;
-                    if (((todo >> blk) & 1ull) && lr < f.n_local_rows && px < f.W)
-                        *(int4*)(f.ids + (size_t)lr * f.W + px) = make_int4(-1, -1, -1, -1);
-                }
+                const int blk = c >> 1, h = c & 1;
+                const int px = 8 * (bx0 + blk) + 4 * h;
+                if (!RT_FILL_NO_STORES && ((todo >> blk) & 1ull) && px < f.W)
+                    *(int4*)(f.ids + (size_t)lr * f.W + px) = make_int4(-1, -1, -1, -1);
             }
         }
     }

@@ -1,6 +1,6 @@
 """Development: per-wave log of one instrumented frame of the persistent kernel (GPU box).
 
-    python tools/wave_log.py [world] [workgroups_per_cu] [width height] -> summary of gpurun_out/wave_log.csv
+    python tools/wave_log.py [world] [workgroups_per_cu] [width height] [scene sub] -> summary of gpurun_out/wave_log.csv
 """
 import os
 import sys
@@ -16,12 +16,13 @@ import _knobs  # noqa: F401  (RTX_* environment knobs -> render-call defaults)
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 wg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 2160)
+scene, sub = (sys.argv[5], int(sys.argv[6])) if len(sys.argv) > 6 else ("scene7", 6)
 out = os.path.join(ROOT, "gpurun_out", f"wave_log_w{world}_g{wg}.csv")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-sr = rt.SceneReader().readScene(os.path.join(ROOT, "scenes", "scene7.test"))
+sr = rt.SceneReader().readScene(os.path.join(ROOT, "scenes", scene + ".test"))
 r = rt.Renderer(0)
 r.set_scene(sr)
-r.build_grid(15, 6)
+r.build_grid(15, sub)
 d_rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
 for _ in range(2):
     r.render_device(d_rgb.data_ptr(), 0, W, H, rank=0, world=world, workgroups_per_cu=wg)
@@ -32,7 +33,7 @@ np.savetxt(out, a, delimiter=",", header="wave,start,exhausted,end,rounds,update
 a = a[a[:, 3] > 0]                                  # waves that ran
 t0 = a[:, 1].min()
 start, exh, end = (a[:, 1] - t0) / 100.0, (a[:, 2] - t0) / 100.0, (a[:, 3] - t0) / 100.0      # microseconds
-print(f"world {world}, {wg} workgroups per CU, {W}x{H}: instrumented kernel {st.trace_ms:.3f} ms, {len(a)} waves ran")
+print(f"{scene}, world {world}, {wg} workgroups per CU, {W}x{H}: instrumented kernel {st.trace_ms:.3f} ms, {len(a)} waves ran")
 print(f"  start   : min {start.min():.0f} median {np.median(start):.0f} max {start.max():.0f} us")
 print(f"  no more pixels after: median {np.median(exh[exh > 0]):.0f} max {exh.max():.0f} us")
 print(f"  end     : percentiles 10/50/90/99/100 = {np.percentile(end, [10, 50, 90, 99, 100]).round(0)} us")
