@@ -286,6 +286,15 @@ int  rtx_frame_times(rtx_ctx* ctx, float* frame_ms, float* kernel_ms);
  * deepest level, helper tasks.  out holds 8 * max_waves values; *n_waves receives the number of waves logged. */
 int  rtx_download_wave_log(rtx_ctx* ctx, uint64_t* out, int64_t max_waves, int64_t* n_waves);
 
+/* Test aid: moves the never-reset counters of the context's frame start close to where they wrap around, so that a
+ * test can render across the wrap.  The persistent pipelines clear nothing per frame: screen tiles and per-tile path
+ * depths carry the frame's number, which starts over after 2^26 frames, and the frame-start kernel's ticket counters
+ * are 32-bit words that simply wrap (a few thousand tickets per frame: every few million frames).  After this call the
+ * context's next frame is `frames_before_wrap` frames before the frame number starts over and `tickets_before_wrap`
+ * tickets before the ticket counters wrap.  Needs a frame rendered on the context before (the counters live in
+ * buffers that the first frame allocates); waits for the device.  It has no counterpart in the reference. */
+int  rtx_debug_set_frame_counters(rtx_ctx* ctx, uint32_t frames_before_wrap, uint32_t tickets_before_wrap);
+
 /* Single-ray probes for tests: the device evaluates Grid::intersect (src/grid.h:259-261) for n rays.
  * origins/dirs: [n][3] host floats (directions are used as given, not normalised); t_limit: [n] or NULL
  * (= FLT_MAX).  out_t [n], out_prim [n] (-1 = miss), out_pos / out_normal [n][3] (nullable). */

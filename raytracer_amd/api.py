@@ -156,6 +156,7 @@ def _load():
         "rtx_frame_status": (C.c_int, [vp]),
         "rtx_frame_times": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "rtx_download_wave_log": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
+        "rtx_debug_set_frame_counters": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
         "rtx_intersect": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "rtx_camera_rays": (C.c_int, [vp, C.POINTER(_Camera), i32, i32, i32, vp, vp]),
         "rtx_quantize": (C.c_int, [vp, C.c_int64, vp]),
@@ -174,7 +175,7 @@ EXPORTED_SYMBOLS = (
     "rtx_strerror", "rtx_last_error", "rtx_scene_load", "rtx_scene_parse", "rtx_scene_free", "rtx_scene_get_view",
     "rtx_scene_get_camera", "rtx_scene_get_size", "rtx_scene_get_output", "rtx_create", "rtx_destroy",
     "rtx_set_scene", "rtx_build_grid", "rtx_get_grid_info", "rtx_download_grid", "rtx_local_rows", "rtx_render",
-    "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_frame_times", "rtx_download_wave_log", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
+    "rtx_render_device", "rtx_render_device_noalloc", "rtx_frame_status", "rtx_frame_times", "rtx_download_wave_log", "rtx_debug_set_frame_counters", "rtx_intersect", "rtx_camera_rays", "rtx_quantize", "rtx_quantize_device",
     "rtx_save_image", "rtx_render_u8", "rtx_save_image_u8", "rtx_multi_create", "rtx_multi_destroy", "rtx_multi_device_count",
     "rtx_multi_set_scene", "rtx_multi_build_grid", "rtx_multi_get_grid_info", "rtx_multi_render", "rtx_multi_render_u8",
     "rtx_multi_render_device")
@@ -417,6 +418,10 @@ class Renderer:
         a, b = C.c_float(), C.c_float()
         _check(_load().rtx_frame_times(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def debug_set_frame_counters(self, frames_before_wrap, tickets_before_wrap):
+        """Test aid: the context's next frame is this many frames / tickets before its never-reset counters wrap."""
+        _check(_load().rtx_debug_set_frame_counters(self._h, frames_before_wrap, tickets_before_wrap))
 
     def wave_log(self):
         """[n_waves, 8] uint64 log of the last frame rendered with count_work (start, exhausted, end, rounds, updates,

@@ -1037,6 +1037,7 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
             // the stamps start over (after 2^26 frames): the maps go back to zeros, on the frame's stream
             HIP_TRY(hipMemsetAsync(ws.tile_map, 0, (size_t)tbx * tby * sizeof(unsigned), st));
             for (int k = 0; k < 2; k++) HIP_TRY(hipMemsetAsync(ws.tile_cost[k], 0, (size_t)tbx * ((nl + 7) / 8) * sizeof(int), st));
+            HIP_TRY(hipMemsetAsync(ws.counters + CNT_TILES_ALL, 0, sizeof(int), st));   // (holds a stamp as well)
             ps->seq = 0;
             hint->valid = false;
         }
@@ -1295,6 +1296,24 @@ int rtx_download_wave_log(rtx_ctx* c, uint64_t* out, int64_t max_waves, int64_t*
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(out, c->work.p + 24, 8 * n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
+    return RTX_OK;
+}
+
+int rtx_debug_set_frame_counters(rtx_ctx* c, uint32_t frames_before_wrap, uint32_t tickets_before_wrap) {
+    if (!c) { rtx_set_error("rtx_debug_set_frame_counters: bad argument"); return RTX_E_INVALID; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { rtx_set_error("hipSetDevice(%d) failed", c->device); return RTX_E_DEVICE; }
+    if (!c->prep_sync.p || c->prep_sync.n < 8) { rtx_set_error("rtx_debug_set_frame_counters: no frame rendered on this context yet"); return RTX_E_STATE; }
+    HIP_TRY(hipDeviceSynchronize());
+    PrepState& ps = c->prep;
+    // (frame numbers only ever grow between wraps, which is all the stamps in the maps need)
+    ps.seq = std::max(ps.seq, RTX_MAX_STAMP - std::min(frames_before_wrap, RTX_MAX_STAMP));
+    const unsigned at = 0u - tickets_before_wrap;
+    unsigned words[8] = {at, at, at, at, at, 0u, 0u, 0u};
+    for (int k = 0; k < 3; k++) ps.ticket[k] = at;
+    for (int k = 0; k < 2; k++) ps.done[k] = at;
+    HIP_TRY(hipMemcpy(c->prep_sync.p, words, sizeof words, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
     return RTX_OK;
 }
 

@@ -666,6 +666,34 @@ def test_schedule_hints_never_change_the_frame(renderer):
                 assert np.array_equal(rgb[rows].view(np.int32), want[1][0][rows].view(np.int32))
 
 
+def test_frames_across_the_wrap_of_the_frame_number_and_of_the_ticket_counters():
+    """Nothing is cleared at the start of a frame of the persistent pipelines: screen tiles and per-tile path depths carry
+    the frame's number, which starts over after 2^26 frames (the maps are zeroed then), and the frame-start kernel's
+    ticket counters are 32-bit words that wrap every few million frames.  A context moved to just before both wraps
+    renders across them, with the previous frame's hint and without, in both persistent pipelines and under a second
+    camera: every frame equals the level-queue pipeline's bit for bit."""
+    r = rt.Renderer(0)
+    try:
+        sr = rt.SceneReader().readScene(scene_path("scene7"))
+        r.set_scene(sr)
+        r.build_grid(15, 6)
+        W, H = 640, 360
+        cams = [sr._camera(), sr._camera()]
+        cams[1].eye[0], cams[1].eye[1] = 9.0, 4.0
+        want = [r.render(W, H, 5, camera=c, level_queues=True)[:2] for c in cams]
+        r.render(W, H, 5, camera=cams[0])                    # (allocates the buffers the counters live in)
+        for frames_before, tickets_before in ((3, 1500), (2, 40), (5, 0)):
+            r.debug_set_frame_counters(frames_before, tickets_before)
+            for k, kw in enumerate(({}, {}, {"generations": True}, {"tile_hint": False}, {}, {"generations": True}, {}, {})):
+                cam = k % 2 if k >= 4 else 0
+                rgb, ids, st = r.render(W, H, 5, camera=cams[cam], **kw)
+                assert np.array_equal(ids, want[cam][1]), (frames_before, tickets_before, k)
+                assert np.array_equal(rgb.view(np.int32), want[cam][0].view(np.int32)), (frames_before, tickets_before, k)
+                assert st.primary_rays == W * H
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("name,sub", [("scene4-specular", 0), ("scene5", 0), ("scene6", 0), ("scene7", 6)])
 def test_both_register_budgets_of_the_frame_kernel(renderer, name, sub):
     """The frame kernel is compiled for three and for four resident waves per SIMD (168 / 128 registers, six / five
