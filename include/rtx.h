@@ -250,7 +250,7 @@ int  rtx_render_u8(rtx_ctx* ctx, const rtx_camera* cam, const rtx_render_params*
  * HIP events of the context.  The call allocates nothing and frees nothing, on
  * the host or on the device: the work cursors, the screen-tile map / classes / list / per-tile depths and the path
  * terms beyond the levels kept in LDS -- which rtx_render_device keeps in buffers the context allocates on first use --
- * live in a 10.2 MB array the library holds on every GPU it runs on for the life of the process.
+ * live in a 10.6 MB array the library holds on every GPU it runs on for the life of the process.
  *   Limits (RTX_E_LIMIT beyond): max_depth <= 6; ceil(width / 8) * ceil(height / 8) <= 131072 (3840 x 2160 fits).
  *   Not available (RTX_E_INVALID): RTX_RENDER_LEVEL_QUEUES, RTX_RENDER_SERIAL_LANES, RTX_RENDER_COUNT_WORK; no stats.
  *   At most 1024 workgroups are launched (workgroups_per_cu is clamped).
