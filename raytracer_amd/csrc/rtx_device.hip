@@ -771,10 +771,12 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         g.fine_off = mk(-g.lo.x * g.inv_fcell.x, -g.lo.y * g.inv_fcell.y, -g.lo.z * g.inv_fcell.z);
         g.fstart = c->fstart.p;
         g.fids = c->fids.p;
-        if ((rc = c->frecs.reserve(3 * (size_t)std::max<int64_t>(gi.n_fine_refs, 1)))) return rc;
+        // (the kernels of a scene with one transform read 3 fields per record, the others 6: see k_expand_records)
+        const int frec_stride = c->n_xforms == 1 ? 3 : 6;
+        if ((rc = c->frecs.reserve((size_t)frec_stride * (size_t)std::max<int64_t>(gi.n_fine_refs, 1)))) return rc;
         if (gi.n_fine_refs > 0)
             hipLaunchKernelGGL(k_expand_records, dim3((unsigned)((gi.n_fine_refs + 255) / 256)), dim3(256), 0, 0, (int)gi.n_fine_refs,
-                               (const int*)c->fids.p, (const float4*)c->prims.p, c->frecs.p);
+                               (const int*)c->fids.p, (const float4*)c->prims.p, (const float*)c->xinv.p, frec_stride, c->frecs.p);
         g.frecs = c->frecs.p;
         g.cocc = c->cocc.p;
         gi.sub = sub;

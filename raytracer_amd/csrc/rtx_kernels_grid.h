@@ -326,16 +326,26 @@ __global__ __launch_bounds__(256) void k_sort_large(const int* long_cells, const
   }
 }
 
-// Per-reference copies of the primitive records in list order (nested grid): frecs[3j..3j+2] = record of fids[j]
-// with the primitive index in the slot that holds the material in the table.
-__global__ void k_expand_records(int n_refs, const int* fids, const float4* prims, float4* frecs) {
+// Per-reference copies of the primitive records in list order (nested grid): frecs[S j .. S j + 2] = record of fids[j]
+// with the primitive index in the slot that holds the material in the table.  S = 3 for a scene with one transform
+// (its inverse lives in scalar registers); otherwise S = 6 and rows 0..2 of the primitive's inverse transform follow
+// the record -- (m0 m1 m2 m4) (m5 m6 m8 m9) (m10 m12 m13 m14) of the column-major 4x4 -- so that a pair's test does not
+// wait for a second load whose address it only learns from the first.
+__global__ void k_expand_records(int n_refs, const int* fids, const float4* prims, const float* xinv, int stride, float4* frecs) {
     const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (j >= n_refs) return;
     const int pid = fids[j];
     const float4 q2 = prims[3 * pid + 2];
-    frecs[3 * (size_t)j] = prims[3 * pid];
-    frecs[3 * (size_t)j + 1] = prims[3 * pid + 1];
-    frecs[3 * (size_t)j + 2] = make_float4(q2.x, q2.y, as_float(pid), q2.w);
+    float4* out = frecs + (size_t)stride * j;
+    out[0] = prims[3 * pid];
+    out[1] = prims[3 * pid + 1];
+    out[2] = make_float4(q2.x, q2.y, as_float(pid), q2.w);
+    if (stride == 6) {
+        const float* m = xinv + 16 * as_int(q2.y);
+        out[3] = make_float4(m[0], m[1], m[2], m[4]);
+        out[4] = make_float4(m[5], m[6], m[8], m[9]);
+        out[5] = make_float4(m[10], m[12], m[13], m[14]);
+    }
 }
 
 // Sparse view of the nested grid, step 1: occupancy mask of every 32 fine cells and its population count

@@ -38,7 +38,7 @@ struct DevGrid {
     const int* fstart;          // fine cell lists (tight padded boxes), CSR over cell = block * cpb + local,
                                 // block = coarse cell index, local = lx + sub * (ly + sub * lz)
     const int* fids;
-    const float4* frecs;        // the primitive records of fids, copied into list order (3 x float4 per reference, the
+    const float4* frecs;        // the primitive records of fids, copied into list order (3 x float4 per reference -- 6, with the inverse transform's rows, when the scene has several transforms --, the
                                 // primitive index in place of the material): a cell's candidates are one contiguous read
     const unsigned char* cocc;  // per coarse cell: 1 if any nested fine cell holds a primitive
     const unsigned* cocc_bits;  // the same as a bit mask, 32 coarse cells per word

@@ -296,13 +296,20 @@ struct Walker {
 // Returns true for a triangle whose divisions are still to be done (numerators in cand, index in cand_pid).
 template <bool SINGLE_XF, bool COUNT, int PRIMS>
 __device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, float4 q0, float4 q1,
-                                          float4 q2, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
+                                          float4 q2, float4 x0, float4 x1, float4 x2, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
+    const bool inverse_in_record = pid < 0;              // (the nested grid's copies carry it, see k_expand_records)
     if (pid < 0) pid = as_int(q2.z);
     if (!SINGLE_XF) {
-        const float* m = sc.xinv + 16 * as_int(q2.y);
         const f3 Ow = Oo, Dw = Do;
-        Oo = mul_point(m, Ow);
-        Do = mul_dir(m, Dw);
+        if (inverse_in_record) {
+            const float m[16] = {x0.x, x0.y, x0.z, 0.0f, x0.w, x1.x, x1.y, 0.0f, x1.z, x1.w, x2.x, 0.0f, x2.y, x2.z, x2.w, 1.0f};
+            Oo = mul_point(m, Ow);
+            Do = mul_dir(m, Dw);
+        } else {
+            const float* m = sc.xinv + 16 * as_int(q2.y);
+            Oo = mul_point(m, Ow);
+            Do = mul_dir(m, Dw);
+        }
         if (COUNT) wc.xform_evals++;
     }
     // PRIMS: 1 = the scene holds only triangles, 2 = only spheres (the other test is compiled out), 0 = both
@@ -449,7 +456,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
         // them one batch ahead, so that the reads of the next batch travel while the current one is computed: worth
         // 3 to 8 % where a frame is bound by the latency of its rays (small images, a rank's share), a loss of 5 %
         // where it is bound by throughput (the registers that hold the second batch).
-        const auto fetch = [&](int base, int& owner, int& pid, float4& q0, float4& q1, float4& q2) {
+        const auto fetch = [&](int base, int& owner, int& pid, float4& q0, float4& q1, float4& q2, float4& x0, float4& x1, float4& x2) {
             l.owner_at[lane] = 0;
             wave_lds_sync();
             if (count > 0 && excl >= base && excl < base + 64) l.owner_at[excl - base] = lane;
@@ -462,24 +469,26 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
                 int rec = as_int(l.ray_b[owner].w) + p;       // position in the concatenated cell lists
                 const float4* recs = g.frecs;                // the nested grid's copies of the records, in list order
                 if (MODE == RT_SEARCH_REF) { pid = rec = g.cids[rec]; recs = sc.prims; }
-                q0 = recs[3 * rec]; q1 = recs[3 * rec + 1]; q2 = recs[3 * rec + 2];
+                constexpr int stride = (MODE == RT_SEARCH_REF || SINGLE_XF) ? 3 : 6;
+                q0 = recs[stride * rec]; q1 = recs[stride * rec + 1]; q2 = recs[stride * rec + 2];
+                if (stride == 6) { x0 = recs[stride * rec + 3]; x1 = recs[stride * rec + 4]; x2 = recs[stride * rec + 5]; }
             }
         };
         int owner = 0, pid = -1;
-        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
-        if (AHEAD) fetch(0, owner, pid, q0, q1, q2);
+        float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, x0 = q0, x1 = q0, x2 = q0;
+        if (AHEAD) fetch(0, owner, pid, q0, q1, q2, x0, x1, x2);
         for (int base = 0; base < total; base += 64) {
             if (COUNT) wc.w_test_batches++;
             int owner_n = 0, pid_n = -1;
-            float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
-            if (!AHEAD) fetch(base, owner, pid, q0, q1, q2);
-            else if (base + 64 < total) fetch(base + 64, owner_n, pid_n, n0, n1, n2);
+            float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0, y0 = n0, y1 = n0, y2 = n0;
+            if (!AHEAD) fetch(base, owner, pid, q0, q1, q2, x0, x1, x2);
+            else if (base + 64 < total) fetch(base + 64, owner_n, pid_n, n0, n1, n2, y0, y1, y2);
             bool queued = false;
             float4 cand = make_float4(0, 0, 0, 0);
             int cand_pid = -1;
             if (base + lane < total) {
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
-                queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, q0, q1, q2, pid,
+                queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, q0, q1, q2, x0, x1, x2, pid,
                                                             cand, cand_pid, wc);
             }
             // The divisions are the dearest part of a triangle test and one pair in five gets that far: the
@@ -503,6 +512,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
             if (AHEAD) {
                 owner = owner_n; pid = pid_n;
                 q0 = n0; q1 = n1; q2 = n2;
+                x0 = y0; x1 = y1; x2 = y2;
             }
         }
         if (q_tail > q_head) {                       // at most 64 left
