@@ -126,6 +126,10 @@ typedef struct rtx_grid_info {
     int64_t n_fine_cells, n_fine_refs;   /* fine cells incl. padding (32 * ceil(sub^3 / 32) per coarse cell) */
     int64_t n_occupied_fine_cells;
     float   build_ms;              /* GPU time of the last rtx_build_grid                           */
+    int32_t skips_repeated_lists;  /* nested grid: 1 if a ray that has tested a fine cell's list skips the cells after it
+                                      that hold the very same list (chosen where at least a quarter of the occupied
+                                      cells share their list with another cell and the scene has several transforms:
+                                      spheres and large triangles in a coarse grid); same hits either way */
 } rtx_grid_info;
 int  rtx_get_grid_info(const rtx_ctx* ctx, rtx_grid_info* out);
 /* Copies a grid's CSR arrays to the host.  which = RTX_GRID_REFERENCE or RTX_GRID_NESTED.

@@ -60,7 +60,8 @@ class _Camera(C.Structure):
 class GridInfo(C.Structure):
     _fields_ = [("lo", C.c_float * 3), ("hi", C.c_float * 3), ("rx", C.c_int32), ("ry", C.c_int32), ("rz", C.c_int32),
                 ("sub", C.c_int32), ("n_cells", C.c_int64), ("n_refs", C.c_int64), ("n_fine_cells", C.c_int64),
-                ("n_fine_refs", C.c_int64), ("n_occupied_fine_cells", C.c_int64), ("build_ms", C.c_float)]
+                ("n_fine_refs", C.c_int64), ("n_occupied_fine_cells", C.c_int64), ("build_ms", C.c_float),
+                ("skips_repeated_lists", C.c_int32)]
 
 
 class _RenderParams(C.Structure):

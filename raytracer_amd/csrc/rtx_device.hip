@@ -170,6 +170,9 @@ struct rtx_ctx {
     DevBuf<unsigned char> cocc;
     DevBuf<unsigned> wmask, cocc_bits;
     DevBuf<int> wpop, wpre, ostart, ocell;
+    DevBuf<int4> oinfo;                        // per occupied fine cell: list start, length, class of equal lists
+    DevBuf<unsigned long long> list_key, class_key;
+    DevBuf<int> class_rep;
     DevBuf<uint2> words;
     DevBuf<float4> frecs;
     DevGrid dgrid{};
@@ -756,12 +759,35 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         if ((rc = c->ostart.reserve((size_t)n_occ + 1)) || (rc = c->ocell.reserve((size_t)std::max(n_occ, 1)))) return rc;
         hipLaunchKernelGGL(k_compact, dim3((n_words + 255) / 256), dim3(256), 0, 0, n_words, (const int*)c->fstart.p, (const unsigned*)c->wmask.p,
                            (const int*)c->wpre.p, c->words.p, c->ostart.p, c->ocell.p);
+        int n_shared = 0;
+        {
+            // classes of equal lists (see k_list_keys): a table of twice as many slots as occupied cells, a power of two
+            int slots = 64;
+            while (slots < 2 * n_occ) slots *= 2;
+            if ((rc = c->oinfo.reserve((size_t)std::max(n_occ, 1))) || (rc = c->list_key.reserve((size_t)std::max(n_occ, 1))) ||
+                (rc = c->class_key.reserve((size_t)slots)) || (rc = c->class_rep.reserve((size_t)slots + 1)))
+                return rc;
+            HIP_TRY(hipMemsetAsync(c->class_key.p, 0, (size_t)slots * sizeof(unsigned long long), 0));
+            HIP_TRY(hipMemsetAsync(c->class_rep.p, 0x7f, (size_t)slots * sizeof(int), 0));
+            HIP_TRY(hipMemsetAsync(c->class_rep.p + slots, 0, sizeof(int), 0));
+            if (n_occ > 0) {
+                hipLaunchKernelGGL(k_list_keys, dim3((n_occ + 255) / 256), dim3(256), 0, 0, n_occ, (const int*)c->ostart.p, (const int*)c->fids.p,
+                                   c->list_key.p, c->class_key.p, c->class_rep.p, slots - 1);
+                hipLaunchKernelGGL(k_list_classes, dim3((n_occ + 255) / 256), dim3(256), 0, 0, n_occ, (const int*)c->ostart.p, (const int*)c->fids.p,
+                                   (const unsigned long long*)c->list_key.p, (const unsigned long long*)c->class_key.p, (const int*)c->class_rep.p,
+                                   slots - 1, c->oinfo.p, c->class_rep.p + slots);
+                HIP_TRY(hipMemcpy(&n_shared, c->class_rep.p + slots, sizeof(int), hipMemcpyDeviceToHost));
+            }
+        }
+        // (worth the look-up inside the walk where at least a quarter of the occupied cells repeat another cell's list:
+        // spheres and large triangles in a coarse nested grid; the dragon's 47 549 lists are all but unique)
+        c->dsparse.skip_repeats = c->n_xforms != 1 && 4 * (int64_t)n_shared >= (int64_t)n_occ && n_shared > 0 ? 1 : 0;
         hipLaunchKernelGGL(k_occupancy, dim3((n_blocks + 255) / 256), dim3(256), 0, 0, n_blocks, wpb, (const unsigned*)c->wmask.p, c->cocc.p);
         if ((rc = c->cocc_bits.reserve((size_t)(n_blocks + 31) / 32))) return rc;
         hipLaunchKernelGGL(k_occupancy_bits, dim3(((n_blocks + 31) / 32 + 255) / 256), dim3(256), 0, 0, n_blocks, (const unsigned char*)c->cocc.p, c->cocc_bits.p);
         g.cocc_bits = c->cocc_bits.p;
         c->dsparse.words = c->words.p;
-        c->dsparse.ostart = c->ostart.p;
+        c->dsparse.lists = c->dsparse.skip_repeats ? (const int*)c->oinfo.p : (const int*)c->ostart.p;
         c->dsparse.words_per_block = wpb;
         g.sub = sub;
         g.cpb = 32 * wpb;
@@ -790,6 +816,7 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     gi.build_ms = ms;
+    gi.skips_repeated_lists = (flags & RTX_GRID_NESTED) ? c->dsparse.skip_repeats : 0;
     return RTX_OK;
 }
 

@@ -369,6 +369,50 @@ __global__ void k_compact(int n_words, const int* fstart, const unsigned* mask, 
         if (m & (1u << b)) { ocell[o] = 32 * w + b; ostart[o++] = fstart[32 * w + b]; }
     if (w == n_words - 1) ostart[wpre[n_words]] = fstart[32 * n_words];
 }
+// Classes of equal lists.  Neighbouring fine cells often hold the same list (a sphere or a large triangle spans many of
+// them): a ray that has just tested a list need not test it again in the next cell that holds the same one.  Every
+// occupied fine cell gets the number of the first occupied cell (compact numbering) whose list is identical -- same
+// primitives, same order -- so that two cells' lists are equal if (not only if) their classes are: cells are
+// keyed by a 64-bit hash of their list in an open-addressing table, the smallest cell number per key is the key's
+// representative, and a cell whose list differs from its representative's (two different lists with one hash) keeps
+// its own number.  info[o] = (list start, list length, class, 0).
+__device__ __forceinline__ unsigned long long list_hash(const int* ids, int n) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)(unsigned)n;
+    for (int i = 0; i < n; i++) {
+        h ^= (unsigned long long)(unsigned)ids[i] + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 33;
+    }
+    return h | 1ull;                                      // (0 marks a free slot of the table)
+}
+__global__ void k_list_keys(int n_occ, const int* ostart, const int* fids, unsigned long long* key, unsigned long long* table_key,
+                            int* table_rep, int table_mask) {
+    const int o = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (o >= n_occ) return;
+    const int b = ostart[o], e = ostart[o + 1];
+    const unsigned long long h = list_hash(fids + b, e - b);
+    key[o] = h;
+    for (int slot = (int)(h >> 17) & table_mask;; slot = (slot + 1) & table_mask) {       // (the table has twice as many slots as cells)
+        const unsigned long long seen = atomicCAS(table_key + slot, 0ull, h);
+        if (seen == 0ull || seen == h) { atomicMin(table_rep + slot, o); return; }
+    }
+}
+__global__ void k_list_classes(int n_occ, const int* ostart, const int* fids, const unsigned long long* key,
+                               const unsigned long long* table_key, const int* table_rep, int table_mask, int4* info, int* n_shared) {
+    const int o = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (o >= n_occ) return;
+    const int b = ostart[o], n = ostart[o + 1] - b;
+    const unsigned long long h = key[o];
+    int slot = (int)(h >> 17) & table_mask;
+    while (table_key[slot] != h) slot = (slot + 1) & table_mask;
+    int cls = table_rep[slot];
+    const int rb = ostart[cls];
+    bool same = ostart[cls + 1] - rb == n;
+    for (int i = 0; same && i < n; i++) same = fids[rb + i] == fids[b + i];
+    if (!same) cls = o;
+    if (cls != o) atomicAdd(n_shared, 1);                 // (cells whose list another cell holds as well)
+    info[o] = make_int4(b, n, cls, 0);
+}
 // coarse-cell occupancy of the nested grid: any fine cell of the block holds a primitive
 __global__ void k_occupancy(int n_blocks, int words_per_block, const unsigned* mask, unsigned char* occ) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);

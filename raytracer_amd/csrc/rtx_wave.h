@@ -6,9 +6,13 @@
 //          occupancy bitmask) until it stands on a cell that holds primitives;
 //   test   the (ray, primitive) candidate pairs of ALL lanes are spread over the 64 lanes: lane p takes
 //          pair p, finds its owner ray from the per-lane prefix sums staged in LDS, reads the owner's
-//          ray from LDS, gathers the primitive and runs the test; accepted hits are folded into the
-//          owner's best hit with a 64-bit LDS atomic min over (t bits, primitive index), which is the
-//          reference's "nearest, first in file order on ties" (src/geometries.h:184-187).
+//          ray from LDS, gathers the primitive and runs the test; hits are folded into the owner's slot
+//          with a 64-bit LDS atomic min over (t bits, primitive index) -- the nearest hit of the list,
+//          the first in file order on ties, whatever its distance; the owner then accepts it if it lies
+//          before the exit of its coarse cell, which is the reference's "nearest with t < t_exit, first
+//          in file order on ties" (src/geometries.h:184-187).  The slot keeps the list's result, so a
+//          ray that meets the same list again in its next cell (a sphere or a large triangle spans many
+//          cells) applies that cell's bound to it instead of testing again (Walker::walk).
 // A ray's dependent-load chain is therefore one round per occupied cell it visits, not one per candidate,
 // and a lane whose ray has finished or has few candidates still runs tests for its neighbours.
 //
@@ -17,22 +21,32 @@
 #pragma once
 #include "rtx_traverse.h"
 
+
 namespace rt {
 
 // Sparse view of the fine grid.  Fine cells are numbered block-major: cell = block * cells_per_block + local,
 // block = coarse cell index, local = lx + sub * (ly + sub * lz), cells_per_block = 32 * words_per_block
 // (padded).  Per 32 cells one uint2: x = occupancy mask, y = number of occupied cells before this word (over
-// the whole grid).  The lists of the occupied cells are CSR over that compact numbering (ostart), ids in fids.
+// the whole grid).  The lists of the occupied cells are CSR over that compact numbering (ids in fids, records in frecs).
+// Where many cells share their list (skip_repeats, set by the host) the walk looks up, per occupied cell it reaches, the
+// class of equal lists the cell belongs to (cells of one class hold identical lists, see k_list_classes) and skips the
+// list it tested last -- one more load inside the walk, so not where lists are all but unique.  `lists` is then an int4
+// per occupied cell (start, length, class, 0), otherwise the plain CSR starts (int per cell, one more at the end: a
+// quarter of the cache footprint).
 struct DevSparse {
     const uint2* words;
-    const int* ostart;
+    const int* lists;
     int words_per_block;
+    int skip_repeats;
 };
 
 struct __attribute__((aligned(16))) WaveLds {
-    float4 ray_a[64];              // ray origin xyz (in the space the tests run in), acceptance bound t < w
+    float4 ray_a[64];              // ray origin xyz (in the space the tests run in), w = class (of equal lists) of the list the
+                                   // ray tested last, -1 = none (kept here, not in a register: the walk only needs it where
+                                   // it skips repeated lists)
     float4 ray_b[64];              // ray direction xyz, w = bits of (list start - exclusive prefix)
-    unsigned long long best[64];   // (t bits << 32) | primitive, all ones = none
+    unsigned long long best[64];   // nearest hit over the list the lane's ray tested last, whatever its distance:
+                                   // (t bits << 32) | primitive, all ones = none
     int owner_at[64];              // per pair slot of the current 64-pair batch: lane whose list starts there, else 0
     // triangle candidates that passed the sign tests and await their divisions (ring of RT_CAND_RING entries)
     float4 cand_n[64];             // numerators of beta, gamma, t and the common denominator
@@ -105,6 +119,28 @@ __device__ __forceinline__ Occupancy stage_occupancy(const DevGrid& g, unsigned*
     for (int i = (int)threadIdx.x; i < n_words; i += (int)blockDim.x) lds_words[i] = g.cocc_bits[i];
     __syncthreads();
     return o;
+}
+
+// Per-lane search state that lives beside the Walker: the ray in the space the tests run in and the best hit.
+struct LaneSearch {
+    bool found;
+    float best_t;
+    int best_prim;
+};
+
+// What the last tested list says under the acceptance bound of the coarse cell the ray is in (src/geometries.h:184-187:
+// nearest with t < bound, the first in file order on ties -- the key orders by t, then by primitive index): folded into
+// the ray's accepted hit.  Called by the ray's own lane, after the tests of a round or when the walk skips a cell that
+// holds the list tested last.
+__device__ __forceinline__ void accept_under(WaveLds& l, LaneSearch& r, float bound) {
+    const unsigned long long b = l.best[lane_id()];
+    const float t = as_float((int)(b >> 32));
+    const unsigned long long have = r.found ? (((unsigned long long)(unsigned)as_int(r.best_t) << 32) | (unsigned)r.best_prim) : RT_BEST_NONE;
+    if (b != RT_BEST_NONE && t < bound && b < have) {
+        r.found = true;
+        r.best_t = t;
+        r.best_prim = (int)(b & 0xffffffffull);
+    }
 }
 
 // Per-lane walk state.  MODE = RT_SEARCH_REF: every coarse cell's reference list is a candidate list.
@@ -213,17 +249,22 @@ struct Walker {
     }
 
     // Walks until the lane stands on a candidate list, finishes, or has used `budget` steps.  Returns true on a
-    // list: start/count are the list's range for the reference lists; for the nested search start is the number
-    // of the occupied fine cell, whose range the caller reads (all lanes at once, after the loop).  Every step either finishes the ray or moves a cell index monotonically toward the
-    // grid boundary, so the walk terminates.
-    template <bool COUNT>
+    // list: start/count are the list's range.  An occupied fine cell that holds the very list the ray tested last is
+    // not a candidate: the same ray against the same primitives gives the same distances, so the result of those tests
+    // -- kept without a bound in the lane's slot -- is folded in under this cell's bound (accept_under) and the walk goes
+    // on.  Every step either finishes the ray or moves a cell index monotonically toward the grid boundary, so the
+    // walk terminates.
+    // SKIP: the skipping is compiled in.  (Its mere presence in the loop costs the kernels that never use it 4 - 5 % -- a
+    // 4K frame of the dragon, 1.2 % repeats: 1.61 -> 1.68 ms with three frames in flight --, so only the kernels for
+    // scenes with several transforms, which are scenes of several objects, carry it.)
+    template <bool COUNT, bool SKIP>
     __device__ __forceinline__ bool walk(const DevGrid& g, const DevSparse& sp, const Occupancy& occ, int budget, int& start,
-                                         int& count, bool found, float best_t, WorkCounters& wc) {
+                                         int& count, WaveLds& l, LaneSearch& r, bool any_hit, WorkCounters& wc) {
         while (state != 2 && budget-- > 0) {
             if (COUNT) wc.w_walk_iters++;
             // one step = leave the fine cell that is done with, enter a coarse cell if the walk stands before one,
             // look at the fine cell the walk stands on: the only copy of each piece of the walk in the kernel
-            if (MODE == RT_SEARCH_NESTED && state == 3) fine_advance(g, found, best_t);
+            if (MODE == RT_SEARCH_NESTED && state == 3) fine_advance(g, r.found, r.best_t);
             if (state == 4) coarse_advance(g);
             if (state == 0) {
                 if (COUNT) wc.cell_steps++;
@@ -267,9 +308,18 @@ struct Walker {
                 if (w != cur_w) { cur = sp.words[w]; cur_w = w; }
                 const unsigned bit = 1u << (local & 31);
                 if (cur.x & bit) {
-                    start = (int)cur.y + __popc(cur.x & (bit - 1u));
-                    count = 1;
-                    return true;
+                    const int cell = (int)cur.y + __popc(cur.x & (bit - 1u));
+                    if (!SKIP || !sp.skip_repeats) { start = cell; count = -1; return true; }      // (the caller reads the list's range)
+                    const int4 info = ((const int4*)sp.lists)[cell];
+                    float& last_class = l.ray_a[lane_id()].w;
+                    if (info.z != as_int(last_class)) {
+                        start = info.x;
+                        count = info.y;
+                        last_class = as_float(info.z);
+                        return true;
+                    }
+                    accept_under(l, r, t_exit);
+                    if (r.found && any_hit) { state = 2; hit = true; continue; }
                 }
                 state = 3;
             }
@@ -295,7 +345,7 @@ struct Walker {
 // per-reference copies, which carry the primitive index where the primitive table carries the material.
 // Returns true for a triangle whose divisions are still to be done (numerators in cand, index in cand_pid).
 template <bool SINGLE_XF, bool COUNT, int PRIMS>
-__device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float bound, float4 q0, float4 q1,
+__device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int owner, f3 Oo, f3 Do, float4 q0, float4 q1,
                                           float4 q2, float4 x0, float4 x1, float4 x2, int pid, float4& cand, int& cand_pid, WorkCounters& wc) {
     const bool inverse_in_record = pid < 0;              // (the nested grid's copies carry it, see k_expand_records)
     if (pid < 0) pid = as_int(q2.z);
@@ -321,7 +371,7 @@ __device__ __forceinline__ bool test_pair(const DevScene& sc, WaveLds& l, int ow
     }
     if (COUNT) wc.sphere_tests++;
     float t;
-    if (hit_sphere(mk(q0.x, q0.y, q0.z), q0.w, Oo, Do, t) && t < bound) {
+    if (hit_sphere(mk(q0.x, q0.y, q0.z), q0.w, Oo, Do, t)) {      // (kept whatever its distance: the ray's own lane applies the bound)
         // t > 0 here, so its bit pattern orders like its value; the low word breaks ties toward the lower index
         const unsigned long long key = ((unsigned long long)(unsigned)as_int(t) << 32) | (unsigned)pid;
         atomicMin(&l.best[owner], key);
@@ -337,7 +387,7 @@ __device__ __forceinline__ void finish_candidates(WaveLds& l, int head, int n) {
         const float4 c = l.cand_n[at];
         const int2 who = l.cand_who[at];
         float t;
-        if (triangle_quotients(c.x, c.y, c.z, c.w, t) && t < l.ray_a[who.x].w) {
+        if (triangle_quotients(c.x, c.y, c.z, c.w, t)) {
             const unsigned long long key = ((unsigned long long)(unsigned)as_int(t) << 32) | (unsigned)who.y;
             atomicMin(&l.best[who.x], key);
         }
@@ -391,13 +441,6 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
     return v;
 }
 
-// Per-lane search state that lives beside the Walker: the ray in the space the tests run in and the best hit.
-struct LaneSearch {
-    bool found;
-    float best_t;
-    int best_prim;
-};
-
 // Starts a new ray on the calling lanes (others keep theirs).  May be called under divergence.  The ray in the
 // space the tests run in goes to the lane's LDS slot here, once: with a single transform in the scene it is taken to
 // object space from the matrix held in scalar registers (src/geometries.h:179-180, same arithmetic for every
@@ -417,7 +460,7 @@ __device__ __forceinline__ void ray_begin(const DevScene& sc, const DevGrid& g, 
         Or = xf_point(xf, O);
         Dr = xf_dir(xf, D);
     }
-    l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, 0.0f);
+    l.ray_a[lane] = make_float4(Or.x, Or.y, Or.z, as_float(-1));
     l.ray_b[lane] = make_float4(Dr.x, Dr.y, Dr.z, 0.0f);
 }
 
@@ -436,11 +479,14 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     int start = 0, count = 0;
     if (COUNT) wc.w_rounds++;
     const unsigned long long c0 = COUNT ? __builtin_readcyclecounter() : 0ull;
-    const bool pending = w.template walk<COUNT>(g, sp, occ, budget, start, count, r.found, r.best_t, wc);
+    const bool pending = w.template walk<COUNT, !SINGLE_XF>(g, sp, occ, budget, start, count, l, r, any_hit, wc);
     if (!pending) count = 0;
-    else if (MODE == RT_SEARCH_NESTED) {
-        const int b = sp.ostart[start], e = sp.ostart[start + 1];
-        start = b; count = e - b;
+    else {
+        if (MODE == RT_SEARCH_NESTED && count < 0) {
+            const int b = sp.lists[start], e = sp.lists[start + 1];
+            start = b; count = e - b;
+        }
+        l.best[lane] = RT_BEST_NONE;                 // (the slot takes the result of this list alone)
     }
     const int incl = wave_inclusive_scan(count);
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -448,7 +494,6 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     if (total > 0) {
         const int excl = incl - count;
         // the ray itself has been in the lane's slot since ray_begin
-        l.ray_a[lane].w = w.t_exit;
         l.ray_b[lane].w = as_float(start - excl);
         int carry = 0;                               // owner of the last pair of the previous batch (wave-uniform)
         int q_head = 0, q_tail = 0;                  // ring positions of the queued triangle candidates (wave-uniform)
@@ -488,7 +533,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
             int cand_pid = -1;
             if (base + lane < total) {
                 const float4 ra = l.ray_a[owner], rb = l.ray_b[owner];
-                queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), ra.w, q0, q1, q2, x0, x1, x2, pid,
+                queued = test_pair<SINGLE_XF, COUNT, PRIMS>(sc, l, owner, mk(ra.x, ra.y, ra.z), mk(rb.x, rb.y, rb.z), q0, q1, q2, x0, x1, x2, pid,
                                                             cand, cand_pid, wc);
             }
             // The divisions are the dearest part of a triangle test and one pair in five gets that far: the
@@ -523,9 +568,7 @@ __device__ __forceinline__ void wave_round(const DevScene& sc, const DevGrid& g,
     wave_lds_sync();                                 // the atomic minima of all lanes land before the owners read them
     const unsigned long long c2 = COUNT ? __builtin_readcyclecounter() : 0ull;
     if (pending) {
-        const unsigned long long b = l.best[lane];
-        r.found = b != RT_BEST_NONE;
-        if (r.found) { r.best_t = as_float((int)(b >> 32)); r.best_prim = (int)(b & 0xffffffffull); }
+        accept_under(l, r, w.t_exit);
         w.after_tests(g, r.found, r.best_t, any_hit);
     }
     if (COUNT) {

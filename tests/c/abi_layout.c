@@ -19,7 +19,7 @@ int main(void) {
     S(rtx_grid_info);
     F(rtx_grid_info, lo); F(rtx_grid_info, hi); F(rtx_grid_info, rx); F(rtx_grid_info, ry); F(rtx_grid_info, rz); F(rtx_grid_info, sub);
     F(rtx_grid_info, n_cells); F(rtx_grid_info, n_refs); F(rtx_grid_info, n_fine_cells); F(rtx_grid_info, n_fine_refs);
-    F(rtx_grid_info, n_occupied_fine_cells); F(rtx_grid_info, build_ms);
+    F(rtx_grid_info, n_occupied_fine_cells); F(rtx_grid_info, build_ms); F(rtx_grid_info, skips_repeated_lists);
     S(rtx_render_params);
     F(rtx_render_params, width); F(rtx_render_params, height); F(rtx_render_params, max_depth); F(rtx_render_params, eps_bias);
     F(rtx_render_params, search); F(rtx_render_params, tile_rows); F(rtx_render_params, rank); F(rtx_render_params, world);

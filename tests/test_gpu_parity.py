@@ -666,6 +666,33 @@ def test_schedule_hints_never_change_the_frame(renderer):
                 assert np.array_equal(rgb[rows].view(np.int32), want[1][0][rows].view(np.int32))
 
 
+def test_rays_skip_the_list_they_tested_in_the_cell_before():
+    """Where many fine cells share their list with another cell -- spheres and large triangles spanning cells of a coarse
+    nested grid -- a ray that has tested a list applies the next cell's bound to that list's kept result instead of
+    testing it again.  The library chooses this per grid (scenes with several transforms only); wherever it does, every
+    pipeline still renders the oracle's frame, and single rays return the oracle's hits bit for bit."""
+    r = rt.Renderer(0)
+    try:
+        chosen = {}
+        for name, sub in (("scene1", 0), ("scene4-specular", 0), ("scene5", 0), ("scene5", 3), ("scene6", 0), ("scene7", 6)):
+            sr = rt.SceneReader().readScene(scene_path(name))
+            r.set_scene(sr)
+            gi = r.build_grid(15, sub)
+            chosen[(name, sub)] = gi.skips_repeated_lists
+            if not gi.skips_repeated_lists:
+                continue
+            W, H = 200, 150
+            ref = RefScene(scene_path(name))
+            rgb_ref, ids_ref = ref.render(W, H, 5)[:2]
+            for kw in PIPELINES.values():
+                rgb, ids, _ = r.render(W, H, 5, **kw)
+                assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+        assert chosen[("scene4-specular", 0)] == 1 and chosen[("scene5", 0)] == 1, chosen
+        assert chosen[("scene7", 6)] == 0 and chosen[("scene1", 0)] == 0, chosen      # (one transform each)
+    finally:
+        r.close()
+
+
 def test_frames_across_the_wrap_of_the_frame_number_and_of_the_ticket_counters():
     """Nothing is cleared at the start of a frame of the persistent pipelines: screen tiles and per-tile path depths carry
     the frame's number, which starts over after 2^26 frames (the maps are zeroed then), and the frame-start kernel's
