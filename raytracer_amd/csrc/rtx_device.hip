@@ -31,8 +31,6 @@
 
 using namespace rt;
 
-// traced-window pixels per resident lane from which the frame kernel runs with four waves per SIMD
-#define RTX_PIXELS_PER_LANE_FOR_4_WAVES 10.0
 // ... from which a frame launched with a share of the workgroups (frames in flight) runs the generation pipeline
 #define RTX_PIXELS_PER_LANE_FOR_GENERATIONS 10.0
 // ... below which a wave carries 32 paths and keeps its other lanes free for the shadow rays of fresh hits from the start
@@ -960,16 +958,17 @@ static int render_frame(rtx_ctx* c, const rtx_camera* cam, const rtx_render_para
     bool whole_frame = f.lr0 == 0 && lr_end == nl && f.bx0 == 0 && f.nbx == (p->width + 7) / 8;
     // nested search, persistent kernel: only the tiles of the window that can see an occupied fine cell are traced
     const int n_row_blocks = f.n_items0 > 0 ? (lr_end - f.lr0 + 7) / 8 : 0;
-    // Register budget of the frame kernel: with many pixels of the traced window per lane of the launch the frame is
-    // bound by throughput and four waves per SIMD win (measured on scene7: 4K frame 2.16 against 2.35 ms); with few
-    // it is a handful of chains of dependent rays per lane and the version with more registers per lane finishes
-    // each ray sooner (1440p and below, an eighth of a 4K frame).  A launch that shares the GPU with other frames
-    // (workgroups_per_cu given) is a different matter: what counts then is how many workgroups of all those launches
-    // a CU holds at a time, four with the smaller budget against three (measured, six frames of one workgroup per CU
-    // in flight: a quarter of the 4K frame 0.59 -> 0.50 ms per frame, an eighth 0.35 -> 0.31).
+    // Register budget of the frame kernel: four waves per SIMD (128 registers) unless the caller asks for three (168).
+    // With many pixels of the traced window per lane the frame is bound by throughput and the fourth wave wins (4K frame
+    // of scene7 2.16 against 2.35 ms); a launch that shares the GPU with other frames fits four of all those launches'
+    // workgroups on a CU instead of three (six frames of one workgroup per CU in flight: a quarter of the 4K frame 0.59 ->
+    // 0.50 ms per frame, an eighth 0.35 -> 0.31).  Frames of a pixel or two per lane used to run the larger budget (each
+    // ray of a chain finished sooner); measured again on this library, lone first frames, three against four waves:
+    // scene5 0.434 / 0.413 ms, scene6 0.992 / 0.908, scene7 at 1280x720 0.834 / 0.802, at 2560x1440 1.625 / 1.463, a half /
+    // quarter / eighth of its 4K frame 1.77 / 1.55, 1.11 / 1.06, 1.00 / 0.91; only scene4-specular (0.312 / 0.332) and scene1
+    // (0.125 / 0.128) still prefer three.
     const double pixels_per_lane = (double)f.n_items0 / ((double)blocks * RTX_BLOCK);
-    int frame_waves = pixels_per_lane >= RTX_PIXELS_PER_LANE_FOR_4_WAVES && blocks >= 2 * c->n_cus ? 4 : 3;
-    if (p->workgroups_per_cu > 0) frame_waves = 4;
+    int frame_waves = 4;
     if (p->flags & RTX_RENDER_WAVES_3) frame_waves = 3;
     if (p->flags & RTX_RENDER_WAVES_4) frame_waves = 4;
     // Pipeline of the persistent launch.  Generations of one kind of ray make every state update dense but end each
