@@ -117,6 +117,9 @@ int  rtx_set_scene(rtx_ctx* ctx, const rtx_scene_view* view);
  * The reference always uses rx = ry = rz = 15 (src/grid.h:37). */
 #define RTX_GRID_REFERENCE 1u
 #define RTX_GRID_NESTED    2u
+/* with RTX_GRID_NESTED: rays test every list they meet, also one they tested in the cell before (see
+ * rtx_grid_info.skips_repeated_lists); for A/B runs and tests -- the frames are the same either way */
+#define RTX_GRID_TEST_REPEATED_LISTS 4u
 int  rtx_build_grid(rtx_ctx* ctx, int32_t rx, int32_t ry, int32_t rz, int32_t sub, uint32_t flags);
 
 typedef struct rtx_grid_info {

@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     SEARCH_NESTED,
     SEARCH_REFERENCE_LISTS,
     GRID_NESTED,
+    GRID_TEST_REPEATED_LISTS,
     GRID_REFERENCE,
     lib_path,
     local_rows,

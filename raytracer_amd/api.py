@@ -17,6 +17,7 @@ SEARCH_REFERENCE_LISTS = 0
 SEARCH_NESTED = 1
 GRID_REFERENCE = 1
 GRID_NESTED = 2
+GRID_TEST_REPEATED_LISTS = 4
 RENDER_COUNT_WORK = 1
 RENDER_SERIAL_LANES = 2
 ORDER_RGB, ORDER_BGR = 0, 1

@@ -779,7 +779,8 @@ int rtx_build_grid(rtx_ctx* c, int32_t rx, int32_t ry, int32_t rz, int32_t sub, 
         }
         // (worth the look-up inside the walk where at least a quarter of the occupied cells repeat another cell's list:
         // spheres and large triangles in a coarse nested grid; the dragon's 47 549 lists are all but unique)
-        c->dsparse.skip_repeats = c->n_xforms != 1 && 4 * (int64_t)n_shared >= (int64_t)n_occ && n_shared > 0 ? 1 : 0;
+        c->dsparse.skip_repeats = c->n_xforms != 1 && 4 * (int64_t)n_shared >= (int64_t)n_occ && n_shared > 0 &&
+                                  !(flags & RTX_GRID_TEST_REPEATED_LISTS) ? 1 : 0;
         hipLaunchKernelGGL(k_occupancy, dim3((n_blocks + 255) / 256), dim3(256), 0, 0, n_blocks, wpb, (const unsigned*)c->wmask.p, c->cocc.p);
         if ((rc = c->cocc_bits.reserve((size_t)(n_blocks + 31) / 32))) return rc;
         hipLaunchKernelGGL(k_occupancy_bits, dim3(((n_blocks + 31) / 32 + 255) / 256), dim3(256), 0, 0, n_blocks, (const unsigned char*)c->cocc.p, c->cocc_bits.p);

@@ -684,9 +684,17 @@ def test_rays_skip_the_list_they_tested_in_the_cell_before():
             W, H = 200, 150
             ref = RefScene(scene_path(name))
             rgb_ref, ids_ref = ref.render(W, H, 5)[:2]
+            frames = []
             for kw in PIPELINES.values():
                 rgb, ids, _ = r.render(W, H, 5, **kw)
                 assert_image_parity(rgb, ids, rgb_ref, ids_ref)
+                frames.append((rgb, ids))
+            # the same grid with every list tested: the same frames, bit for bit
+            gi = r.build_grid(15, sub, rt.GRID_REFERENCE | rt.GRID_NESTED | rt.GRID_TEST_REPEATED_LISTS)
+            assert gi.skips_repeated_lists == 0
+            for kw, (rgb_skip, ids_skip) in zip(PIPELINES.values(), frames):
+                rgb, ids, _ = r.render(W, H, 5, **kw)
+                assert np.array_equal(ids, ids_skip) and np.array_equal(rgb.view(np.int32), rgb_skip.view(np.int32))
         assert chosen[("scene4-specular", 0)] == 1 and chosen[("scene5", 0)] == 1, chosen
         assert chosen[("scene7", 6)] == 0 and chosen[("scene1", 0)] == 0, chosen      # (one transform each)
     finally:
