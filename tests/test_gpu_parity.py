@@ -1017,6 +1017,52 @@ def test_several_gpus_behind_one_handle_leave_the_callers_device_alone(renderer)
         torch.cuda.set_device(0)
 
 
+def test_frames_in_flight_over_several_handles_from_several_threads():
+    """A caller of the C ABI keeps frames in flight across GPUs with several rtx_multi handles, one per host thread (a
+    handle renders one frame at a time), each launch with a share of the workgroups.  Three handles of two ranks each
+    on this machine's GPU render different cameras at the same time, several frames each: every frame equals the
+    single-context frame of its camera bit for bit."""
+    import threading
+    sr = rt.SceneReader().readScene(scene_path("scene7"))
+    W, H = 480, 270
+    cams = [sr._camera() for _ in range(3)]
+    cams[1].eye[0], cams[1].eye[1] = 9.0, 4.0
+    cams[2].fov_deg = 14.0
+    one = rt.Renderer(0)
+    try:
+        one.set_scene(sr)
+        one.build_grid(15, 6)
+        want = [one.render(W, H, 5, camera=c)[:2] for c in cams]
+    finally:
+        one.close()
+    handles = [rt.MultiRenderer([0, 0]) for _ in cams]
+    errors = []
+    try:
+        for m in handles:
+            m.set_scene(sr)
+            m.build_grid(15, 6)
+
+        def work(k):
+            try:
+                for _ in range(6):
+                    rgb, ids, _ = handles[k].render(W, H, 5, camera=cams[k], workgroups_per_cu=1)
+                    if not (np.array_equal(ids, want[k][1]) and np.array_equal(rgb.view(np.int32), want[k][0].view(np.int32))):
+                        errors.append(f"handle {k}: frame differs")
+            except Exception as e:                         # noqa: BLE001  (reported by the main thread)
+                errors.append(f"handle {k}: {e}")
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(handles))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        assert not any(t.is_alive() for t in threads), "a render call did not return"
+        assert not errors, errors
+    finally:
+        for m in handles:
+            m.close()
+
+
 def test_eight_bit_frame_is_converted_on_the_device(renderer):
     load(renderer, "scene4-specular")
     want, want_ids, _ = renderer.render(333, 211, 5)
