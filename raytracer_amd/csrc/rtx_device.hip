@@ -401,8 +401,9 @@ void launch_level_w(rtx_ctx* c, const DevScene& sc, const DevFrame& f, int level
 template <int MODE, bool SINGLE_XF, int PRIMS, int WAVES>
 void launch_frame4(rtx_ctx* c, const DevScene& sc, const DevFrame& f, float4* ps, int blocks, hipStream_t st, bool count, int levels, bool gen) {
     if (gen) {
-        if (count) hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
-        else hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        const int gen_blocks = blocks * (RTX_BLOCK / RTX_GEN_BLOCK);
+        if (count) hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(gen_blocks), dim3(RTX_GEN_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
+        else hipLaunchKernelGGL((k_frame_gen<MODE, SINGLE_XF, false, PRIMS, WAVES>), dim3(gen_blocks), dim3(RTX_GEN_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);
         return;
     }
     if (count) hipLaunchKernelGGL((k_frame<MODE, SINGLE_XF, true, PRIMS, WAVES>), dim3(blocks), dim3(RTX_BLOCK), 0, st, sc, c->dgrid, c->dsparse, f, ps, levels);

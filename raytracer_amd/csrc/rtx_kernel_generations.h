@@ -37,6 +37,13 @@
 // either.  Live paths: at most the requests on both stacks plus the 64 rays of the generation in flight, fewer than
 // RTX_GEN_PATHS.
 // ---------------------------------------------------------------------------------------------------
+// Lanes per workgroup of the generation kernel (a multiple of 64 that divides RTX_BLOCK).  Its waves share nothing but
+// the 0.5 KB copy of the coarse occupancy bits, and a workgroup gives its place on the CU back only when its last wave
+// has ended: with one wave per workgroup a wave that has run dry makes room at once for a wave of another frame in
+// flight (three 4K frames in flight 1.587 -> 1.571 ms per frame, four halves 0.856 -> 0.842; two waves per workgroup 1.593).
+#ifndef RTX_GEN_BLOCK
+#define RTX_GEN_BLOCK 64
+#endif
 #define RTX_GEN_CAP 128
 #define RTX_GEN_S_FIELDS 3
 #define RTX_GEN_M_FIELDS 2
@@ -50,13 +57,13 @@ __host__ __device__ constexpr size_t rtx_gen_wave_f4(int n_levels) {
 #define RT_GEN_WAVES_MIN 0         // (development: hold the generation kernel's allocation to at least this many waves per SIMD)
 #endif
 template <int MODE, bool SINGLE_XF, bool COUNT, int PRIMS, int WAVES>
-__global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_GEN_WAVES_MIN)) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_levels) {
-    __shared__ WaveLds lds[RTX_BLOCK / 64];
-    __shared__ int hit_count[RTX_BLOCK / 64][RTX_MAX_LEVELS];
+__global__ __launch_bounds__(RTX_GEN_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_GEN_WAVES_MIN)) void k_frame_gen(DevScene sc, DevGrid g, DevSparse sp, DevFrame f, float4* queues, int n_levels) {
+    __shared__ WaveLds lds[RTX_GEN_BLOCK / 64];
+    __shared__ int hit_count[RTX_GEN_BLOCK / 64][RTX_MAX_LEVELS];
     // per path slot: low half = what is outstanding for the path, high half = 1 + its deepest level with a term (once
     // its chain has ended, 0 before)
-    __shared__ int path_state[RTX_BLOCK / 64][RTX_GEN_PATHS];
-    __shared__ unsigned short free_slot[RTX_BLOCK / 64][RTX_GEN_PATHS];
+    __shared__ int path_state[RTX_GEN_BLOCK / 64][RTX_GEN_PATHS];
+    __shared__ unsigned short free_slot[RTX_GEN_BLOCK / 64][RTX_GEN_PATHS];
     __shared__ unsigned occ_lds[RT_OCC_LDS_WORDS];
     const Occupancy occ = stage_occupancy(g, occ_lds);
     const XfRegs xf = {};
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_G
     if (lane < RTX_MAX_LEVELS) hit_count[wave][lane] = 0;
     for (int i = lane; i < RTX_GEN_PATHS; i += 64) free_slot[wave][i] = (unsigned short)i;
     int n_free = RTX_GEN_PATHS;                         // free path slots (wave-uniform): free_slot[0 .. n_free)
-    float4* const qS = queues + (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave) * rtx_gen_wave_f4(n_levels);
+    float4* const qS = queues + (size_t)(blockIdx.x * (RTX_GEN_BLOCK / 64) + wave) * rtx_gen_wave_f4(n_levels);
     float4* const qM = qS + RTX_GEN_CAP * RTX_GEN_S_FIELDS;
     int2* const path_pixel = (int2*)(qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS);   // per path slot: local pixel index, 8x8 block of the cost map
     float4* const terms = qM + RTX_GEN_CAP * RTX_GEN_M_FIELDS + RTX_GEN_PATHS / 2;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_G
     int log_rounds = 0, log_updates = 0, log_pixels = 0, log_deepest = 0;
     if (COUNT) log_start = wall_clock64();
     const unsigned long long below = (1ull << lane) - 1ull;
-    fill_untraced_blocks(f, (int)blockIdx.x * (RTX_BLOCK / 64) + wave, (int)gridDim.x * (RTX_BLOCK / 64));
+    fill_untraced_blocks(f, (int)blockIdx.x * (RTX_GEN_BLOCK / 64) + wave, (int)gridDim.x * (RTX_GEN_BLOCK / 64));
 
     for (;;) {
         // ---- which generation ----------------------------------------------------------------------------------
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_G
             }
             // the last pixels of the frame are shared out among the waves (at least 32 a generation)
             const int left = max(n_items - (base + nC), 0);
-            const int waves = (int)gridDim.x * (RTX_BLOCK / 64);
+            const int waves = (int)gridDim.x * (RTX_GEN_BLOCK / 64);
             new_paths = min(64, max(left / waves + 1, 32));
             if (left < fu.endgame_pixels) endgame = true;
         }
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(RTX_BLOCK, (WAVES > RT_GEN_WAVES_MIN ? WAVES : RT_G
             deepest = max(deepest, __shfl_down(deepest, off));
         }
         if (lane == 0) {
-            unsigned long long* log = f.work + 24 + 8 * (size_t)(blockIdx.x * (RTX_BLOCK / 64) + wave);
+            unsigned long long* log = f.work + 24 + 8 * (size_t)(blockIdx.x * (RTX_GEN_BLOCK / 64) + wave);
             log[0] = log_start; log[1] = log_exhausted; log[2] = wall_clock64(); log[3] = (unsigned long long)log_rounds;
             log[4] = (unsigned long long)log_updates; log[5] = (unsigned long long)pixels; log[6] = (unsigned long long)deepest;
             log[7] = 0ull;
